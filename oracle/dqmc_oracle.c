@@ -1,0 +1,984 @@
+/*
+ * dqmc_oracle.c — CPU ORACLE. TEST INFRASTRUCTURE ONLY (see dqmc_oracle.h).
+ *
+ * Literal single-threaded restatement of MonteCarlo.jl's DQMC hot path.  Every
+ * function cites the reference file:line it follows (paths relative to
+ * /root/reference).  Loop nests keep the reference's summation order (k runs
+ * 1..K sequentially for every output element); the reference's @avx macro
+ * only changes SIMD association, which is CPU dependent even in Julia.
+ */
+#include "dqmc_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------ */
+/* lattices                                                                  */
+/* ------------------------------------------------------------------------ */
+
+/* src/lattices/square.jl:25-60.  lattice = reshape(1:L^2,(L,L)) (column-major:
+ * site(i,j) = i + L*j, 0-based i,j).  circshift(lattice,(-1,0))[i,j] =
+ * lattice[i+1,j] -> "up"; (0,-1) -> lattice[i,j+1] "right"; (1,0) -> "down";
+ * (0,1) -> "left".  neighs rows = up,right,down,left; column = site. */
+void orc_square_neighs(int L, int64_t *neighs)
+{
+    for (int j = 0; j < L; ++j)
+        for (int i = 0; i < L; ++i) {
+            int s = i + L * j;
+            int up = (i + 1) % L + L * j;
+            int right = i + L * ((j + 1) % L);
+            int down = (i + L - 1) % L + L * j;
+            int left = i + L * ((j + L - 1) % L);
+            neighs[4 * s + 0] = up + 1;
+            neighs[4 * s + 1] = right + 1;
+            neighs[4 * s + 2] = down + 1;
+            neighs[4 * s + 3] = left + 1;
+        }
+}
+
+/* src/lattices/square.jl:30-43: for src in lattice: (src,up,0), (src,right,0) */
+void orc_square_bonds(int L, int64_t *bonds)
+{
+    int N = L * L, nb = 2 * N;
+    int64_t *neighs = (int64_t *)malloc(sizeof(int64_t) * 4 * N);
+    orc_square_neighs(L, neighs);
+    int id = 0;
+    for (int s = 0; s < N; ++s) {
+        bonds[id + 0 * nb] = s + 1;
+        bonds[id + 1 * nb] = neighs[4 * s + 0];
+        bonds[id + 2 * nb] = 0;
+        ++id;
+        bonds[id + 0 * nb] = s + 1;
+        bonds[id + 1 * nb] = neighs[4 * s + 1];
+        bonds[id + 2 * nb] = 0;
+        ++id;
+    }
+    free(neighs);
+}
+
+/* src/flavors/DQMC/abstract.jl:23-54 (bonds = neighbors(l) = undirected bond
+ * table, src/lattices/abstract.jl:106-108) */
+int orc_build_checkerboard(int n_sites, int n_bonds, const int64_t *bonds,
+                           int64_t *cb, int64_t *gstart, int64_t *gend,
+                           int max_groups)
+{
+    int *edges_used = (int *)calloc(n_bonds, sizeof(int));
+    int *sites_used = (int *)malloc(sizeof(int) * n_sites);
+    int group_start = 1, group_end = 1, ngroups = 0;
+    for (;;) {
+        int any_unused = 0;
+        for (int e = 0; e < n_bonds; ++e)
+            if (!edges_used[e]) any_unused = 1;
+        if (!any_unused) break;
+        memset(sites_used, 0, sizeof(int) * n_sites);
+        for (int id = 0; id < n_bonds; ++id) {
+            int src = (int)bonds[id + 0 * n_bonds], trg = (int)bonds[id + 1 * n_bonds];
+            if (edges_used[id]) continue;
+            if (sites_used[src - 1]) continue;
+            if (sites_used[trg - 1]) continue;
+            edges_used[id] = 1;
+            sites_used[src - 1] = 1;
+            sites_used[trg - 1] = 1;
+            cb[3 * (group_end - 1) + 0] = src;
+            cb[3 * (group_end - 1) + 1] = trg;
+            cb[3 * (group_end - 1) + 2] = id + 1;
+            ++group_end;
+        }
+        if (ngroups < max_groups) {
+            gstart[ngroups] = group_start;
+            gend[ngroups] = group_end - 1;
+        }
+        ++ngroups;
+        group_start = group_end;
+    }
+    free(edges_used);
+    free(sites_used);
+    return ngroups;
+}
+
+/* HubbardModelAttractive.jl:78-91 (T = diagm(-mu); T[trg,src] += -t over
+ * neighbors(l, Val(true)) = src-major, up,right,down,left);
+ * HubbardModelRepulsive.jl:87-100 is the same with mu = 0. */
+void orc_hopping_square(int L, double t, double mu, double *T)
+{
+    int N = L * L;
+    int64_t *neighs = (int64_t *)malloc(sizeof(int64_t) * 4 * N);
+    orc_square_neighs(L, neighs);
+    memset(T, 0, sizeof(double) * N * N);
+    for (int i = 0; i < N; ++i) T[i + N * i] = -mu;
+    for (int src = 0; src < N; ++src)
+        for (int d = 0; d < 4; ++d) {
+            int trg = (int)neighs[4 * src + d] - 1;
+            T[trg + N * src] += -t;
+        }
+    free(neighs);
+}
+
+/* ------------------------------------------------------------------------ */
+/* linalg: src/linalg/general.jl                                            */
+/* ------------------------------------------------------------------------ */
+
+/* general.jl:7-15.  Cmn = sum_k A[m,k]*B[k,n], k ascending.  Written in axpy
+ * form (k middle loop) so that the inner loop is unit-stride; each C[m,n]
+ * still accumulates k = 1..K in order. */
+void orc_vmul_nn(int n, double *C, const double *A, const double *B)
+{
+    for (int j = 0; j < n; ++j) {
+        double *c = C + (size_t)n * j;
+        for (int m = 0; m < n; ++m) c[m] = 0.0;
+        for (int k = 0; k < n; ++k) {
+            const double b = B[k + (size_t)n * j];
+            const double *a = A + (size_t)n * k;
+            for (int m = 0; m < n; ++m) c[m] += a[m] * b;
+        }
+    }
+}
+/* general.jl:26-35: C = A * B' */
+void orc_vmul_nt(int n, double *C, const double *A, const double *B)
+{
+    for (int j = 0; j < n; ++j) {
+        double *c = C + (size_t)n * j;
+        for (int m = 0; m < n; ++m) c[m] = 0.0;
+        for (int k = 0; k < n; ++k) {
+            const double b = B[j + (size_t)n * k];
+            const double *a = A + (size_t)n * k;
+            for (int m = 0; m < n; ++m) c[m] += a[m] * b;
+        }
+    }
+}
+/* general.jl:36-45: C = A' * B */
+void orc_vmul_tn(int n, double *C, const double *A, const double *B)
+{
+    for (int j = 0; j < n; ++j)
+        for (int m = 0; m < n; ++m) {
+            const double *a = A + (size_t)n * m, *b = B + (size_t)n * j;
+            double s = 0.0;
+            for (int k = 0; k < n; ++k) s += a[k] * b[k];
+            C[m + (size_t)n * j] = s;
+        }
+}
+/* general.jl:46-56: C = A' * B' */
+void orc_vmul_tt(int n, double *C, const double *A, const double *B)
+{
+    for (int j = 0; j < n; ++j)
+        for (int m = 0; m < n; ++m) {
+            const double *a = A + (size_t)n * m;
+            double s = 0.0;
+            for (int k = 0; k < n; ++k) s += a[k] * B[j + (size_t)n * k];
+            C[m + (size_t)n * j] = s;
+        }
+}
+/* general.jl:16-20 */
+void orc_vmul_nd(int n, double *C, const double *A, const double *d)
+{
+    for (int j = 0; j < n; ++j)
+        for (int m = 0; m < n; ++m) C[m + (size_t)n * j] = A[m + (size_t)n * j] * d[j];
+}
+/* general.jl:21-25 */
+void orc_vmul_dn(int n, double *C, const double *d, const double *B)
+{
+    for (int j = 0; j < n; ++j)
+        for (int m = 0; m < n; ++m) C[m + (size_t)n * j] = d[m] * B[m + (size_t)n * j];
+}
+
+/* general.jl:138-166 */
+void orc_rdivp(int n, double *A, const double *T, double *O, const int64_t *pivot)
+{
+    for (int j = 0; j < n; ++j) {
+        int p = (int)pivot[j] - 1;
+        for (int i = 0; i < n; ++i) O[i + (size_t)n * j] = A[i + (size_t)n * p];
+    }
+    for (int i = 0; i < n; ++i) A[i] = O[i] / T[0];
+    for (int j = 1; j < n; ++j) {
+        double *aj = A + (size_t)n * j;
+        const double *oj = O + (size_t)n * j;
+        for (int i = 0; i < n; ++i) aj[i] = oj[i];
+        for (int k = 0; k < j; ++k) { /* x -= A[i,k]*T[k,j], k ascending */
+            const double t = T[k + (size_t)n * j];
+            const double *ak = A + (size_t)n * k;
+            for (int i = 0; i < n; ++i) aj[i] -= ak[i] * t;
+        }
+        const double tjj = T[j + (size_t)n * j];
+        for (int i = 0; i < n; ++i) aj[i] = aj[i] / tjj;
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* UDT: src/linalg/UDT.jl                                                   */
+/* ------------------------------------------------------------------------ */
+
+/* UDT.jl:151-168: from-scratch column norms of the trailing block; strict '>'
+ * keeps the first maximum. */
+static int indmaxcolumn(int n, const double *A, int j, double *maxval)
+{
+    double max = 0.0;
+    for (int k = j; k < n; ++k) max += A[k + (size_t)n * j] * A[k + (size_t)n * j];
+    int ii = j;
+    for (int i = j + 1; i < n; ++i) {
+        double mi = 0.0;
+        for (int k = j; k < n; ++k) mi += A[k + (size_t)n * i] * A[k + (size_t)n * i];
+        if (fabs(mi) > max) {
+            max = mi;
+            ii = i;
+        }
+    }
+    *maxval = max;
+    return ii;
+}
+
+/* UDT.jl:133-148 */
+static double reflector(int n, double *x, double normu, int j)
+{
+    double xi1 = x[j + (size_t)n * j];
+    if (normu == 0.0) return 0.0;
+    normu = sqrt(normu);
+    double nu = copysign(normu, xi1);
+    xi1 += nu;
+    x[j + (size_t)n * j] = -nu;
+    for (int i = j + 1; i < n; ++i) x[i + (size_t)n * j] /= xi1;
+    return xi1 / nu;
+}
+
+/* UDT.jl:32-50 applied to view(input, j:n, j+1:n) with x = view(input, j:n, j) */
+static void reflector_apply(int n, double *A, int j, double tau)
+{
+    const double *x = A + (size_t)n * j;
+    for (int c = j + 1; c < n; ++c) {
+        double *a = A + (size_t)n * c;
+        double vAj = a[j];
+        for (int i = j + 1; i < n; ++i) vAj += x[i] * a[i];
+        vAj = tau * vAj;
+        a[j] -= vAj;
+        for (int i = j + 1; i < n; ++i) a[i] -= x[i] * vAj;
+    }
+}
+
+/* UDT.jl:192-306 */
+void orc_udt_pivot(int n, double *U, double *D, double *input, int64_t *pivot,
+                   double *temp, int apply_pivot)
+{
+    for (int i = 0; i < n; ++i) pivot[i] = i + 1;
+
+    for (int j = 0; j < n; ++j) {
+        double maxval;
+        int jm = indmaxcolumn(n, input, j, &maxval);
+        if (jm != j) {
+            int64_t tp = pivot[jm];
+            pivot[jm] = pivot[j];
+            pivot[j] = tp;
+            for (int i = 0; i < n; ++i) {
+                double tmp = input[i + (size_t)n * jm];
+                input[i + (size_t)n * jm] = input[i + (size_t)n * j];
+                input[i + (size_t)n * j] = tmp;
+            }
+        }
+        double tau = reflector(n, input, maxval, j);
+        temp[j] = tau;
+        reflector_apply(n, input, j, tau);
+    }
+
+    /* "Calculate Q", UDT.jl:250-266 */
+    for (size_t i = 0; i < (size_t)n * n; ++i) U[i] = 0.0;
+    for (int i = 0; i < n; ++i) U[i + (size_t)n * i] = 1.0;
+    U[(n - 1) + (size_t)n * (n - 1)] -= temp[n - 1];
+    for (int k = n - 2; k >= 0; --k) {
+        const double *x = input + (size_t)n * k;
+        for (int j = k; j < n; ++j) {
+            double *u = U + (size_t)n * j;
+            double vBj = u[k];
+            for (int i = k + 1; i < n; ++i) vBj += x[i] * u[i];
+            vBj = temp[k] * vBj;
+            u[k] -= vBj;
+            for (int i = k + 1; i < n; ++i) u[i] -= x[i] * vBj;
+        }
+    }
+
+    for (int i = 0; i < n; ++i) D[i] = fabs(input[i + (size_t)n * i]);
+
+    if (apply_pivot) { /* UDT.jl:283-297 */
+        for (int i = 0; i < n; ++i) {
+            double d = 1.0 / D[i];
+            for (int j = 0; j < i; ++j) temp[pivot[j] - 1] = 0.0;
+            for (int j = i; j < n; ++j) temp[pivot[j] - 1] = d * input[i + (size_t)n * j];
+            for (int j = 0; j < n; ++j) input[i + (size_t)n * j] = temp[j];
+        }
+    } else { /* UDT.jl:298-306: upper part only, sub-diagonal left dirty */
+        for (int i = 0; i < n; ++i) {
+            double d = 1.0 / D[i];
+            for (int j = i; j < n; ++j) input[i + (size_t)n * j] = d * input[i + (size_t)n * j];
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* calculate_greens_AVX!: src/flavors/DQMC/stack.jl:337-393                 */
+/* ------------------------------------------------------------------------ */
+void orc_calculate_greens(int n, double *Ul, double *Dl, double *Tl, double *Ur,
+                          double *Dr, double *Tr, double *G, int64_t *pivot,
+                          double *temp)
+{
+    orc_vmul_nt(n, G, Tl, Tr);                       /* :346 */
+    orc_vmul_nd(n, Tr, G, Dr);                       /* :347 */
+    orc_vmul_dn(n, G, Dl, Tr);                       /* :348 */
+    orc_udt_pivot(n, Tr, Dr, G, pivot, temp, 0);     /* :349 */
+    orc_vmul_nn(n, Tl, Ul, Tr);                      /* :360 */
+    orc_rdivp(n, Ur, G, Ul, pivot);                  /* :361 */
+    orc_vmul_tn(n, Tr, Tl, Ur);                      /* :362 */
+    for (int i = 0; i < n; ++i) Tr[i + (size_t)n * i] += Dr[i]; /* :368 rvadd! */
+    orc_udt_pivot(n, Ul, Dr, Tr, pivot, temp, 0);    /* :376 */
+    orc_rdivp(n, Ur, Tr, G, pivot);                  /* :377 */
+    orc_vmul_nn(n, Tr, Tl, Ul);                      /* :378 */
+    for (int i = 0; i < n; ++i) Dl[i] = 1.0 / Dr[i]; /* :382-384 */
+    orc_vmul_nd(n, Ul, Ur, Dl);                      /* :390 */
+    orc_vmul_nt(n, G, Ul, Tr);                       /* :391 */
+}
+
+/* ------------------------------------------------------------------------ */
+/* RNG                                                                       */
+/* ------------------------------------------------------------------------ */
+static inline void philox_round(uint32_t *c, const uint32_t *k)
+{
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k[0];
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k[1];
+    uint32_t n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+/* Philox4x32-10 (Salmon et al. 2011), counter = (index, 0), key = seed. */
+double orc_philox_uniform(uint64_t seed, uint64_t index)
+{
+    uint32_t c[4] = {(uint32_t)index, (uint32_t)(index >> 32), 0u, 0u};
+    uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k);
+        k[0] += 0x9E3779B9u;
+        k[1] += 0xBB67AE85u;
+    }
+    uint64_t hi = c[0] >> 5, lo = c[1] >> 6; /* 27 + 26 = 53 bits */
+    return (double)((hi << 26) | lo) * (1.0 / 9007199254740992.0);
+}
+
+/* ------------------------------------------------------------------------ */
+/* the DQMC object                                                           */
+/* ------------------------------------------------------------------------ */
+struct orc_mc {
+    int N, nb, n, model, M, s, K; /* n = N (per block); nb blocks */
+    double dtau, U, lambda;
+    int check_prop, check_sign;
+    /* constants, nb x n x n each */
+    double *eT, *eTinv, *eT2, *eTinv2;
+    int8_t *conf; /* N x M */
+    /* stack, per block b: slot i at [(b*(K+1)+i)*n*n] */
+    double *u_stack, *d_stack, *t_stack;
+    double *Ul, *Ur, *Tl, *Tr, *Dl, *Dr, *greens, *greens_temp, *tmp1, *tmp2, *curr_U, *eV;
+    int64_t *pivot;
+    double *tempv;
+    int current_slice, direction;
+    /* rng */
+    int rng_mode; /* 0 = uniform array, 1 = philox */
+    double *uni;
+    size_t n_uni, uni_pos;
+    uint64_t seed, draw;
+    orc_stats st;
+};
+
+static void magstats_init(orc_magstats *s)
+{
+    s->max = -INFINITY;
+    s->min = INFINITY;
+    s->sum = 0.0;
+    s->count = 0;
+}
+/* DQMC.jl:14-20 */
+static void magstats_push(orc_magstats *s, double value)
+{
+    double v = log10(fabs(value));
+    s->max = fmax(s->max, v);
+    s->min = fmin(s->min, v);
+    s->sum += v;
+    s->count += 1;
+}
+
+static double *dalloc(size_t n)
+{
+    double *p = (double *)calloc(n ? n : 1, sizeof(double));
+    if (!p) {
+        fprintf(stderr, "dqmc_oracle: out of memory\n");
+        abort();
+    }
+    return p;
+}
+
+orc_mc *orc_create(int n_sites, int model_kind, int slices, int safe_mult,
+                   double delta_tau, double U, const double *eT,
+                   const double *eTinv, const double *eT2, const double *eTinv2,
+                   int check_prop, int check_sign)
+{
+    if (slices % safe_mult != 0) return NULL; /* stack.jl:115 convert(Int, M/s) throws */
+    orc_mc *mc = (orc_mc *)calloc(1, sizeof(orc_mc));
+    mc->N = n_sites;
+    mc->n = n_sites;
+    mc->model = model_kind;
+    mc->nb = model_kind == ORC_REPULSIVE ? 2 : 1;
+    mc->M = slices;
+    mc->s = safe_mult;
+    mc->K = slices / safe_mult;
+    mc->dtau = delta_tau;
+    mc->U = U;
+    mc->lambda = acosh(exp(0.5 * U * delta_tau)); /* Attractive.jl:103, Repulsive.jl:116 */
+    mc->check_prop = check_prop;
+    mc->check_sign = check_sign;
+    size_t nn = (size_t)mc->n * mc->n, nb = mc->nb;
+    mc->eT = dalloc(nb * nn);
+    mc->eTinv = dalloc(nb * nn);
+    mc->eT2 = dalloc(nb * nn);
+    mc->eTinv2 = dalloc(nb * nn);
+    memcpy(mc->eT, eT, sizeof(double) * nb * nn);
+    memcpy(mc->eTinv, eTinv, sizeof(double) * nb * nn);
+    memcpy(mc->eT2, eT2, sizeof(double) * nb * nn);
+    memcpy(mc->eTinv2, eTinv2, sizeof(double) * nb * nn);
+    mc->conf = (int8_t *)calloc((size_t)mc->N * mc->M, 1);
+    for (size_t i = 0; i < (size_t)mc->N * mc->M; ++i) mc->conf[i] = 1;
+    size_t ne = mc->K + 1;
+    mc->u_stack = dalloc(nb * ne * nn);
+    mc->t_stack = dalloc(nb * ne * nn);
+    mc->d_stack = dalloc(nb * ne * mc->n);
+    mc->Ul = dalloc(nb * nn); mc->Ur = dalloc(nb * nn);
+    mc->Tl = dalloc(nb * nn); mc->Tr = dalloc(nb * nn);
+    mc->Dl = dalloc(nb * mc->n); mc->Dr = dalloc(nb * mc->n);
+    mc->greens = dalloc(nb * nn); mc->greens_temp = dalloc(nb * nn);
+    mc->tmp1 = dalloc(nb * nn); mc->tmp2 = dalloc(nb * nn);
+    mc->curr_U = dalloc(nb * nn);
+    mc->eV = dalloc(nb * mc->n);
+    mc->pivot = (int64_t *)calloc(nb * mc->n, sizeof(int64_t));
+    mc->tempv = dalloc(nb * mc->n);
+    mc->rng_mode = 1;
+    mc->seed = 0;
+    magstats_init(&mc->st.imaginary_probability);
+    magstats_init(&mc->st.negative_probability);
+    magstats_init(&mc->st.propagation_error);
+    orc_init_stack(mc);
+    return mc;
+}
+
+void orc_destroy(orc_mc *mc)
+{
+    if (!mc) return;
+    free(mc->eT); free(mc->eTinv); free(mc->eT2); free(mc->eTinv2); free(mc->conf);
+    free(mc->u_stack); free(mc->t_stack); free(mc->d_stack);
+    free(mc->Ul); free(mc->Ur); free(mc->Tl); free(mc->Tr); free(mc->Dl); free(mc->Dr);
+    free(mc->greens); free(mc->greens_temp); free(mc->tmp1); free(mc->tmp2);
+    free(mc->curr_U); free(mc->eV); free(mc->pivot); free(mc->tempv); free(mc->uni);
+    free(mc);
+}
+
+int orc_nblocks(const orc_mc *mc) { return mc->nb; }
+void orc_set_conf(orc_mc *mc, const int8_t *c) { memcpy(mc->conf, c, (size_t)mc->N * mc->M); }
+void orc_get_conf(const orc_mc *mc, int8_t *c) { memcpy(c, mc->conf, (size_t)mc->N * mc->M); }
+void orc_set_uniforms(orc_mc *mc, const double *u, size_t n)
+{
+    free(mc->uni);
+    mc->uni = dalloc(n);
+    memcpy(mc->uni, u, sizeof(double) * n);
+    mc->n_uni = n;
+    mc->uni_pos = 0;
+    mc->rng_mode = 0;
+}
+size_t orc_uniforms_used(const orc_mc *mc) { return mc->rng_mode == 0 ? mc->uni_pos : (size_t)mc->draw; }
+void orc_seed(orc_mc *mc, uint64_t seed)
+{
+    mc->rng_mode = 1;
+    mc->seed = seed;
+    mc->draw = 0;
+}
+static double next_uniform(orc_mc *mc)
+{
+    if (mc->rng_mode == 0) {
+        if (mc->uni_pos >= mc->n_uni) {
+            fprintf(stderr, "dqmc_oracle: uniform stream exhausted\n");
+            abort();
+        }
+        return mc->uni[mc->uni_pos++];
+    }
+    return orc_philox_uniform(mc->seed, mc->draw++);
+}
+
+static void set_identity(int n, double *A)
+{
+    memset(A, 0, sizeof(double) * (size_t)n * n);
+    for (int i = 0; i < n; ++i) A[i + (size_t)n * i] = 1.0;
+}
+static void set_ones(int n, double *d)
+{
+    for (int i = 0; i < n; ++i) d[i] = 1.0;
+}
+
+#define NN ((size_t)mc->n * mc->n)
+#define USLOT(b, i) (mc->u_stack + ((size_t)(b) * (mc->K + 1) + (i)) * NN)
+#define TSLOT(b, i) (mc->t_stack + ((size_t)(b) * (mc->K + 1) + (i)) * NN)
+#define DSLOT(b, i) (mc->d_stack + ((size_t)(b) * (mc->K + 1) + (i)) * mc->n)
+#define BLK(p, b) ((p) + (size_t)(b) * NN)
+#define VBLK(p, b) ((p) + (size_t)(b) * mc->n)
+
+/* stack.jl:108-159 */
+void orc_init_stack(orc_mc *mc)
+{
+    for (int b = 0; b < mc->nb; ++b) {
+        set_identity(mc->n, BLK(mc->Ul, b));
+        set_identity(mc->n, BLK(mc->Ur, b));
+        set_identity(mc->n, BLK(mc->Tl, b));
+        set_identity(mc->n, BLK(mc->Tr, b));
+        set_ones(mc->n, VBLK(mc->Dl, b));
+        set_ones(mc->n, VBLK(mc->Dr, b));
+    }
+    mc->current_slice = 0;
+    mc->direction = 0;
+}
+
+/* interaction_matrix_exp!: Attractive.jl:100-110, Repulsive.jl:113-126.
+ * slice 1-based; eV is nb x n.  block 0: exp(+sign*lambda*conf), block 1 (repulsive
+ * only): exp(-sign*lambda*conf). */
+static void interaction_matrix_exp(orc_mc *mc, int slice, double power)
+{
+    double sg = power > 0 ? 1.0 : (power < 0 ? -1.0 : 0.0);
+    const int8_t *c = mc->conf + (size_t)mc->N * (slice - 1);
+    for (int i = 0; i < mc->N; ++i) mc->eV[i] = exp(sg * mc->lambda * c[i]);
+    if (mc->nb == 2)
+        for (int i = 0; i < mc->N; ++i) mc->eV[i + mc->N] = exp(-sg * mc->lambda * c[i]);
+}
+
+/* slice_matrices.jl:23-39 into tmp2 (all blocks) */
+static void slice_matrix_into(orc_mc *mc, int slice, double power, double *result)
+{
+    interaction_matrix_exp(mc, slice, power);
+    for (int b = 0; b < mc->nb; ++b) {
+        if (power > 0)
+            orc_vmul_nd(mc->n, BLK(result, b), BLK(mc->eT2, b), VBLK(mc->eV, b));
+        else
+            orc_vmul_dn(mc->n, BLK(result, b), VBLK(mc->eV, b), BLK(mc->eTinv2, b));
+    }
+}
+void orc_slice_matrix(orc_mc *mc, int slice, double power, double *out)
+{
+    slice_matrix_into(mc, slice, power, out);
+}
+
+static void copy_all(orc_mc *mc, double *dst, const double *src)
+{
+    memcpy(dst, src, sizeof(double) * mc->nb * NN);
+}
+
+/* slice_matrices.jl:42-48 */
+static void multiply_slice_matrix_left(orc_mc *mc, int slice, double *Mx)
+{
+    slice_matrix_into(mc, slice, 1.0, mc->tmp2);
+    for (int b = 0; b < mc->nb; ++b) orc_vmul_nn(mc->n, BLK(mc->tmp1, b), BLK(mc->tmp2, b), BLK(Mx, b));
+    copy_all(mc, Mx, mc->tmp1);
+}
+/* slice_matrices.jl:49-55 */
+static void multiply_slice_matrix_right(orc_mc *mc, int slice, double *Mx)
+{
+    slice_matrix_into(mc, slice, 1.0, mc->tmp2);
+    for (int b = 0; b < mc->nb; ++b) orc_vmul_nn(mc->n, BLK(mc->tmp1, b), BLK(Mx, b), BLK(mc->tmp2, b));
+    copy_all(mc, Mx, mc->tmp1);
+}
+/* slice_matrices.jl:56-62 */
+static void multiply_slice_matrix_inv_right(orc_mc *mc, int slice, double *Mx)
+{
+    slice_matrix_into(mc, slice, -1.0, mc->tmp2);
+    for (int b = 0; b < mc->nb; ++b) orc_vmul_nn(mc->n, BLK(mc->tmp1, b), BLK(Mx, b), BLK(mc->tmp2, b));
+    copy_all(mc, Mx, mc->tmp1);
+}
+/* slice_matrices.jl:63-69 */
+static void multiply_slice_matrix_inv_left(orc_mc *mc, int slice, double *Mx)
+{
+    slice_matrix_into(mc, slice, -1.0, mc->tmp2);
+    for (int b = 0; b < mc->nb; ++b) orc_vmul_nn(mc->n, BLK(mc->tmp1, b), BLK(mc->tmp2, b), BLK(Mx, b));
+    copy_all(mc, Mx, mc->tmp1);
+}
+/* slice_matrices.jl:70-76 */
+static void multiply_daggered_slice_matrix_left(orc_mc *mc, int slice, double *Mx)
+{
+    slice_matrix_into(mc, slice, 1.0, mc->tmp2);
+    for (int b = 0; b < mc->nb; ++b) orc_vmul_tn(mc->n, BLK(mc->tmp1, b), BLK(mc->tmp2, b), BLK(Mx, b));
+    copy_all(mc, Mx, mc->tmp1);
+}
+
+/* stack.jl:272-288; idx is 1-based as in the reference; ranges[idx] = (idx-1)s+1 : idx*s */
+static void add_slice_sequence_left(orc_mc *mc, int idx)
+{
+    for (int b = 0; b < mc->nb; ++b) memcpy(BLK(mc->curr_U, b), USLOT(b, idx - 1), sizeof(double) * NN);
+    for (int slice = (idx - 1) * mc->s + 1; slice <= idx * mc->s; ++slice)
+        multiply_slice_matrix_left(mc, slice, mc->curr_U);
+    for (int b = 0; b < mc->nb; ++b) {
+        orc_vmul_nd(mc->n, BLK(mc->tmp1, b), BLK(mc->curr_U, b), DSLOT(b, idx - 1));
+        orc_udt_pivot(mc->n, USLOT(b, idx), DSLOT(b, idx), BLK(mc->tmp1, b), VBLK(mc->pivot, b),
+                      VBLK(mc->tempv, b), 1);
+        orc_vmul_nn(mc->n, TSLOT(b, idx), BLK(mc->tmp1, b), TSLOT(b, idx - 1));
+    }
+}
+/* stack.jl:297-311 */
+static void add_slice_sequence_right(orc_mc *mc, int idx)
+{
+    for (int b = 0; b < mc->nb; ++b) memcpy(BLK(mc->curr_U, b), USLOT(b, idx), sizeof(double) * NN);
+    for (int slice = idx * mc->s; slice >= (idx - 1) * mc->s + 1; --slice)
+        multiply_daggered_slice_matrix_left(mc, slice, mc->curr_U);
+    for (int b = 0; b < mc->nb; ++b) {
+        orc_vmul_nd(mc->n, BLK(mc->tmp1, b), BLK(mc->curr_U, b), DSLOT(b, idx));
+        orc_udt_pivot(mc->n, USLOT(b, idx - 1), DSLOT(b, idx - 1), BLK(mc->tmp1, b), VBLK(mc->pivot, b),
+                      VBLK(mc->tempv, b), 1);
+        orc_vmul_nn(mc->n, TSLOT(b, idx - 1), BLK(mc->tmp1, b), TSLOT(b, idx));
+    }
+}
+
+/* stack.jl:242-255 */
+void orc_build_stack(orc_mc *mc)
+{
+    for (int b = 0; b < mc->nb; ++b) {
+        set_identity(mc->n, USLOT(b, 0));
+        set_ones(mc->n, DSLOT(b, 0));
+        set_identity(mc->n, TSLOT(b, 0));
+    }
+    for (int i = 1; i <= mc->K; ++i) add_slice_sequence_left(mc, i);
+    mc->current_slice = mc->M + 1;
+    mc->direction = -1;
+}
+
+/* stack.jl:406-413 */
+static void calculate_greens_stack(orc_mc *mc, double *out)
+{
+    for (int b = 0; b < mc->nb; ++b)
+        orc_calculate_greens(mc->n, BLK(mc->Ul, b), VBLK(mc->Dl, b), BLK(mc->Tl, b), BLK(mc->Ur, b),
+                             VBLK(mc->Dr, b), BLK(mc->Tr, b), BLK(out, b), VBLK(mc->pivot, b),
+                             VBLK(mc->tempv, b));
+}
+
+/* stack.jl:491-500 */
+void orc_wrap_greens(orc_mc *mc, double *gf, int curr_slice, int direction)
+{
+    if (direction == -1) {
+        multiply_slice_matrix_inv_left(mc, curr_slice - 1, gf);
+        multiply_slice_matrix_right(mc, curr_slice - 1, gf);
+    } else {
+        multiply_slice_matrix_left(mc, curr_slice, gf);
+        multiply_slice_matrix_inv_right(mc, curr_slice, gf);
+    }
+}
+
+static void load_slot(orc_mc *mc, double *U, double *D, double *T, int slot0)
+{
+    for (int b = 0; b < mc->nb; ++b) {
+        memcpy(BLK(U, b), USLOT(b, slot0), sizeof(double) * NN);
+        memcpy(VBLK(D, b), DSLOT(b, slot0), sizeof(double) * mc->n);
+        memcpy(BLK(T, b), TSLOT(b, slot0), sizeof(double) * NN);
+    }
+}
+static void reset_slot(orc_mc *mc, int slot0)
+{
+    for (int b = 0; b < mc->nb; ++b) {
+        set_identity(mc->n, USLOT(b, slot0));
+        set_ones(mc->n, DSLOT(b, slot0));
+        set_identity(mc->n, TSLOT(b, slot0));
+    }
+}
+static void check_propagation(orc_mc *mc)
+{
+    /* stack.jl:538-549 / :602-611: maximum(abs.(greens_temp - greens)) > 1e-7 */
+    double d = 0.0;
+    size_t tot = mc->nb * NN;
+    for (size_t i = 0; i < tot; ++i) {
+        double x = fabs(mc->greens_temp[i] - mc->greens[i]);
+        if (x > d || x != x) d = x;
+    }
+    if (d > 1e-7) magstats_push(&mc->st.propagation_error, d);
+}
+
+/* stack.jl:502-631 */
+void orc_propagate(orc_mc *mc)
+{
+    const int M = mc->M, s = mc->s;
+    if (mc->direction == 1) {
+        if (mc->current_slice % s == 0) {
+            mc->current_slice += 1;
+            if (mc->current_slice == 1) {
+                load_slot(mc, mc->Ur, mc->Dr, mc->Tr, 0);
+                reset_slot(mc, 0);
+                load_slot(mc, mc->Ul, mc->Dl, mc->Tl, 0);
+                calculate_greens_stack(mc, mc->greens);
+            } else if (1 < mc->current_slice && mc->current_slice <= M) {
+                int idx = (mc->current_slice - 1) / s;
+                load_slot(mc, mc->Ur, mc->Dr, mc->Tr, idx);
+                add_slice_sequence_left(mc, idx);
+                load_slot(mc, mc->Ul, mc->Dl, mc->Tl, idx);
+                if (mc->check_prop) copy_all(mc, mc->greens_temp, mc->greens);
+                orc_wrap_greens(mc, mc->greens_temp, mc->current_slice - 1, 1); /* :534-536 unconditional */
+                calculate_greens_stack(mc, mc->greens);
+                if (mc->check_prop) check_propagation(mc);
+            } else {
+                int idx = mc->K; /* n_elements - 1 */
+                add_slice_sequence_left(mc, idx);
+                mc->direction = -1;
+                mc->current_slice = M + 1;
+                orc_propagate(mc);
+            }
+        } else {
+            orc_wrap_greens(mc, mc->greens, mc->current_slice, 1);
+            mc->current_slice += 1;
+        }
+    } else {
+        if ((mc->current_slice - 1) % s == 0) {
+            mc->current_slice -= 1;
+            if (mc->current_slice == M) {
+                load_slot(mc, mc->Ul, mc->Dl, mc->Tl, mc->K);
+                reset_slot(mc, mc->K);
+                load_slot(mc, mc->Ur, mc->Dr, mc->Tr, mc->K);
+                calculate_greens_stack(mc, mc->greens);
+                orc_wrap_greens(mc, mc->greens, mc->current_slice + 1, -1);
+            } else if (0 < mc->current_slice && mc->current_slice < M) {
+                int idx = mc->current_slice / s + 1;
+                load_slot(mc, mc->Ul, mc->Dl, mc->Tl, idx - 1);
+                add_slice_sequence_right(mc, idx);
+                load_slot(mc, mc->Ur, mc->Dr, mc->Tr, idx - 1);
+                if (mc->check_prop) copy_all(mc, mc->greens_temp, mc->greens);
+                calculate_greens_stack(mc, mc->greens);
+                if (mc->check_prop) check_propagation(mc);
+                orc_wrap_greens(mc, mc->greens, mc->current_slice + 1, -1);
+            } else {
+                add_slice_sequence_right(mc, 1);
+                mc->direction = 1;
+                mc->current_slice = 0;
+                orc_propagate(mc);
+            }
+        } else {
+            orc_wrap_greens(mc, mc->greens, mc->current_slice, -1);
+            mc->current_slice -= 1;
+        }
+    }
+}
+
+/* DQMC.jl:546-582 with propose_local/accept_local! of
+ * Attractive.jl:113-155 and Repulsive.jl:128-232 */
+void orc_sweep_spatial(orc_mc *mc)
+{
+    const int N = mc->N, n = mc->n, l = mc->current_slice;
+    int8_t *c = mc->conf + (size_t)N * (l - 1);
+    double *IG = mc->tmp1, *Gr = mc->tmp2; /* scratch vectors (model.IG / model.G) */
+    for (int i = 0; i < N; ++i) {
+        double detratio, dE_boson, gamma = 0.0, R[2] = {0, 0}, Dl_[2] = {0, 0};
+        if (mc->model == ORC_ATTRACTIVE) {
+            dE_boson = -2.0 * mc->lambda * c[i];
+            gamma = exp(dE_boson) - 1.0;
+            double r = 1.0 + gamma * (1.0 - mc->greens[i + (size_t)n * i]);
+            detratio = r * r;
+        } else {
+            double dE = -2.0 * mc->lambda * c[i];
+            Dl_[0] = exp(dE) - 1.0;
+            Dl_[1] = exp(-dE) - 1.0;
+            const double *G1 = BLK(mc->greens, 0), *G2 = BLK(mc->greens, 1);
+            R[0] = 1.0 + Dl_[0] * (1.0 - G1[i + (size_t)n * i]);
+            R[1] = 1.0 + Dl_[1] * (1.0 - G2[i + (size_t)n * i]);
+            /* R12 = -D1*G[i,i+N], R21 = -D2*G[i+N,i]: structurally 0 (blockdiagonal.jl:71-83) */
+            detratio = R[0] * R[1] - (-Dl_[0] * 0.0) * (-Dl_[1] * 0.0);
+            dE_boson = 0.0;
+        }
+        mc->st.prop_local += 1;
+        if (mc->check_sign) {
+            /* imaginary part is identically 0 for real models (DQMC.jl:555-561) */
+            if (detratio < 0.0) magstats_push(&mc->st.negative_probability, detratio);
+        }
+        double p = exp(-dE_boson) * detratio;
+        if (p > 1.0 || next_uniform(mc) < p) { /* DQMC.jl:573 short-circuit */
+            if (mc->model == ORC_ATTRACTIVE) {
+                double *G = mc->greens;
+                for (int j = 0; j < n; ++j) {
+                    IG[j] = -G[j + (size_t)n * i];
+                    Gr[j] = G[i + (size_t)n * j];
+                }
+                IG[i] += 1.0;
+                double x = gamma / (1.0 + gamma * IG[i]);
+                for (int ll = 0; ll < n; ++ll)
+                    for (int k = 0; k < n; ++k) G[k + (size_t)n * ll] -= IG[k] * x * Gr[ll];
+            } else {
+                /* Repulsive.jl:174-181 invert R in place; :191 RD = R*Delta */
+                double inv_div = 1.0 / detratio;
+                double Rinv0 = R[1] * inv_div, Rinv1 = R[0] * inv_div;
+                double RD[2] = {Rinv0 * Dl_[0], Rinv1 * Dl_[1]};
+                for (int b = 0; b < 2; ++b) {
+                    double *G = BLK(mc->greens, b);
+                    for (int m = 0; m < n; ++m) IG[m] = -G[m + (size_t)n * i];
+                    IG[i] += 1.0;
+                    for (int m = 0; m < n; ++m) IG[m] = IG[m] * RD[b]; /* IGR */
+                    for (int m = 0; m < n; ++m) Gr[m] = G[i + (size_t)n * m];
+                    for (int nn_ = 0; nn_ < n; ++nn_)
+                        for (int m = 0; m < n; ++m) {
+                            double t = IG[m] * Gr[nn_];
+                            G[m + (size_t)n * nn_] = G[m + (size_t)n * nn_] - t;
+                        }
+                }
+            }
+            c[i] = (int8_t)-c[i];
+            mc->st.acc_local += 1;
+        }
+    }
+}
+
+void orc_update(orc_mc *mc)
+{
+    orc_propagate(mc);
+    orc_sweep_spatial(mc);
+}
+void orc_prepare(orc_mc *mc)
+{
+    orc_init_stack(mc);
+    orc_build_stack(mc);
+    orc_propagate(mc);
+}
+void orc_sweeps(orc_mc *mc, int n_sweeps)
+{
+    for (int i = 0; i < n_sweeps; ++i)
+        for (int u = 0; u < 2 * mc->M; ++u) orc_update(mc);
+}
+int orc_update_until_measure(orc_mc *mc)
+{
+    int cnt = 0;
+    do {
+        orc_update(mc);
+        ++cnt;
+    } while (!(mc->current_slice == 1 && mc->direction == 1));
+    return cnt;
+}
+
+/* stack.jl:422-480 */
+void orc_calculate_greens_at(orc_mc *mc, int slice, double *out)
+{
+    const int M = mc->M, s = mc->s;
+    for (int b = 0; b < mc->nb; ++b) {
+        set_identity(mc->n, BLK(mc->curr_U, b));
+        set_identity(mc->n, BLK(mc->Ur, b));
+        set_ones(mc->n, VBLK(mc->Dr, b));
+        set_identity(mc->n, BLK(mc->Tr, b));
+    }
+    if (slice + 1 <= M) {
+        for (int k = M; k >= slice + 1; --k) {
+            multiply_daggered_slice_matrix_left(mc, k, mc->curr_U);
+            if (k % s == 0) {
+                for (int b = 0; b < mc->nb; ++b) {
+                    orc_vmul_nd(mc->n, BLK(mc->tmp1, b), BLK(mc->curr_U, b), VBLK(mc->Dr, b));
+                    orc_udt_pivot(mc->n, BLK(mc->curr_U, b), VBLK(mc->Dr, b), BLK(mc->tmp1, b),
+                                  VBLK(mc->pivot, b), VBLK(mc->tempv, b), 1);
+                    memcpy(BLK(mc->tmp2, b), BLK(mc->Tr, b), sizeof(double) * NN);
+                    orc_vmul_nn(mc->n, BLK(mc->Tr, b), BLK(mc->tmp1, b), BLK(mc->tmp2, b));
+                }
+            }
+        }
+        for (int b = 0; b < mc->nb; ++b) {
+            orc_vmul_nd(mc->n, BLK(mc->tmp1, b), BLK(mc->curr_U, b), VBLK(mc->Dr, b));
+            orc_udt_pivot(mc->n, BLK(mc->Ur, b), VBLK(mc->Dr, b), BLK(mc->tmp1, b), VBLK(mc->pivot, b),
+                          VBLK(mc->tempv, b), 1);
+            memcpy(BLK(mc->tmp2, b), BLK(mc->Tr, b), sizeof(double) * NN);
+            orc_vmul_nn(mc->n, BLK(mc->Tr, b), BLK(mc->tmp1, b), BLK(mc->tmp2, b));
+        }
+    }
+    for (int b = 0; b < mc->nb; ++b) {
+        set_identity(mc->n, BLK(mc->curr_U, b));
+        set_identity(mc->n, BLK(mc->Ul, b));
+        set_ones(mc->n, VBLK(mc->Dl, b));
+        set_identity(mc->n, BLK(mc->Tl, b));
+    }
+    if (slice >= 1) {
+        for (int k = 1; k <= slice; ++k) {
+            multiply_slice_matrix_left(mc, k, mc->curr_U);
+            if (k % s == 0) {
+                for (int b = 0; b < mc->nb; ++b) {
+                    orc_vmul_nd(mc->n, BLK(mc->tmp1, b), BLK(mc->curr_U, b), VBLK(mc->Dl, b));
+                    orc_udt_pivot(mc->n, BLK(mc->curr_U, b), VBLK(mc->Dl, b), BLK(mc->tmp1, b),
+                                  VBLK(mc->pivot, b), VBLK(mc->tempv, b), 1);
+                    memcpy(BLK(mc->tmp2, b), BLK(mc->Tl, b), sizeof(double) * NN);
+                    orc_vmul_nn(mc->n, BLK(mc->Tl, b), BLK(mc->tmp1, b), BLK(mc->tmp2, b));
+                }
+            }
+        }
+        for (int b = 0; b < mc->nb; ++b) {
+            orc_vmul_nd(mc->n, BLK(mc->tmp1, b), BLK(mc->curr_U, b), VBLK(mc->Dl, b));
+            orc_udt_pivot(mc->n, BLK(mc->Ul, b), VBLK(mc->Dl, b), BLK(mc->tmp1, b), VBLK(mc->pivot, b),
+                          VBLK(mc->tempv, b), 1);
+            memcpy(BLK(mc->tmp2, b), BLK(mc->Tl, b), sizeof(double) * NN);
+            orc_vmul_nn(mc->n, BLK(mc->Tl, b), BLK(mc->tmp1, b), BLK(mc->tmp2, b));
+        }
+    }
+    calculate_greens_stack(mc, out);
+}
+
+void orc_get_greens_eff(const orc_mc *mc, double *out)
+{
+    memcpy(out, mc->greens, sizeof(double) * mc->nb * (size_t)mc->n * mc->n);
+}
+void orc_set_greens_eff(orc_mc *mc, const double *in)
+{
+    memcpy(mc->greens, in, sizeof(double) * mc->nb * (size_t)mc->n * mc->n);
+}
+/* DQMC.jl:721-730: temp = greens*eT; out = eTinv*temp */
+void orc_get_greens(orc_mc *mc, double *out)
+{
+    double *tmp = dalloc(NN);
+    for (int b = 0; b < mc->nb; ++b) {
+        orc_vmul_nn(mc->n, tmp, BLK(mc->greens, b), BLK(mc->eT, b));
+        orc_vmul_nn(mc->n, BLK(out, b), BLK(mc->eTinv, b), tmp);
+    }
+    free(tmp);
+}
+int orc_current_slice(const orc_mc *mc) { return mc->current_slice; }
+int orc_direction(const orc_mc *mc) { return mc->direction; }
+void orc_get_stats(const orc_mc *mc, orc_stats *st) { *st = mc->st; }
+
+/* ------------------------------------------------------------------------ */
+/* config 1: classical Ising Metropolis (CPU plumbing only)                  */
+/* MC.jl:316-333, IsingModel.jl:83-101,177-185, Ising/measurements.jl:30-94 */
+/* ------------------------------------------------------------------------ */
+void orc_ising_run(int L, double beta, int thermalization, int sweeps,
+                   uint64_t seed, int8_t *conf_io, orc_ising_result *res)
+{
+    int N = L * L;
+    int64_t *neighs = (int64_t *)malloc(sizeof(int64_t) * 4 * N);
+    orc_square_neighs(L, neighs);
+    int8_t *c = (int8_t *)malloc(N);
+    uint64_t draw = 0;
+    if (conf_io) memcpy(c, conf_io, N);
+    else
+        for (int i = 0; i < N; ++i) c[i] = orc_philox_uniform(seed, draw++) < 0.5 ? -1 : 1;
+    /* energy(): IsingModel.jl:177-185 */
+    double E = 0.0;
+    for (int i = 0; i < N; ++i)
+        E -= c[i] * c[neighs[4 * i + 0] - 1] + c[i] * c[neighs[4 * i + 1] - 1];
+    memset(res, 0, sizeof(*res));
+    for (int sw = 1; sw <= thermalization + sweeps; ++sw) {
+        for (int i = 0; i < N; ++i) {
+            double dE = 2.0 * c[i] *
+                        (c[neighs[4 * i + 0] - 1] + c[neighs[4 * i + 1] - 1] +
+                         c[neighs[4 * i + 2] - 1] + c[neighs[4 * i + 3] - 1]);
+            res->proposed += 1;
+            if (dE <= 0 || orc_philox_uniform(seed, draw++) < exp(-beta * dE)) {
+                E += dE;
+                c[i] = (int8_t)-c[i];
+                res->accepted += 1;
+            }
+        }
+        if (sw > thermalization) { /* measure_rate = 1 */
+            double Mg = 0.0;
+            for (int i = 0; i < N; ++i) Mg += c[i];
+            Mg = fabs(Mg);
+            res->E += E;
+            res->E2 += E * E;
+            res->M += Mg;
+            res->M2 += Mg * Mg;
+            res->n_meas += 1;
+        }
+    }
+    if (conf_io) memcpy(conf_io, c, N);
+    free(c);
+    free(neighs);
+}

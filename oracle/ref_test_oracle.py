@@ -1,0 +1,130 @@
+"""Independent oracles restated from the reference's own TESTS. TEST INFRASTRUCTURE ONLY.
+
+1. The LAPACK-QR Green's function oracle of test/testfunctions.jl:10-118 with
+   decompose_udt of test/linalg/old_linalg.jl:16-24.  Julia's qr(A, Val(true))
+   is LAPACK dgeqp3, which scipy.linalg.qr(pivoting=True) calls as well, so this
+   is an implementation of G that shares no code with oracle/dqmc_oracle.c
+   (different QR, different pivot rule, dense inverses).
+2. Exact diagonalisation of the 2x2 Hubbard model, test/ED/ED.jl:68-120 (Hamiltonian)
+   and :497-518 (equal-time Green's function), used at test/ED/ED_tests.jl:91-176.
+"""
+import numpy as np
+import scipy.linalg as sla
+
+
+# --------------------------------------------------------------------------
+# test/linalg/old_linalg.jl:16-24
+def decompose_udt(A):
+    Q, R, p = sla.qr(A, pivoting=True)
+    pinv = np.empty_like(p)
+    pinv[p] = np.arange(len(p))
+    D = np.abs(np.diag(R))
+    T = (R / D[:, None])[:, pinv]
+    return Q, D, T
+
+
+def slice_matrix(eT2, lam, conf, slice_, sign=+1.0):
+    """slice_matrices.jl:10-21 for the attractive model; slice_ is 1-based.
+    `sign` = +1 gives block 0 / attractive, -1 the second (down) block of the
+    repulsive model (Repulsive.jl:113-126)."""
+    eV = np.exp(sign * lam * conf[:, slice_ - 1].astype(np.float64))
+    return eT2 * eV[None, :]
+
+
+# test/testfunctions.jl:10-42: Ul,Dl,Tl = B(stop)...B(start)
+def slice_matrix_chain(B, start, stop, safe_mult):
+    n = B(1).shape[0]
+    U = np.eye(n); D = np.ones(n); T = np.eye(n)
+    for k in range(start, stop + 1):
+        U = B(k) @ U
+        if k % safe_mult == 0:
+            U = U * D[None, :]
+            U, D, Tnew = decompose_udt(U)
+            T = Tnew @ T
+    U = U * D[None, :]
+    U, D, Tnew = decompose_udt(U)
+    T = Tnew @ T
+    return U, D, T
+
+
+# test/testfunctions.jl:45-77: Ur,Dr,Tr = B(start)' ... B(stop)'
+def slice_matrix_chain_dagger(B, start, stop, safe_mult):
+    n = B(1).shape[0]
+    U = np.eye(n); D = np.ones(n); T = np.eye(n)
+    for k in range(stop, start - 1, -1):
+        U = B(k).T @ U
+        if k % safe_mult == 0:
+            U = U * D[None, :]
+            U, D, Tnew = decompose_udt(U)
+            T = Tnew @ T
+    U = U * D[None, :]
+    U, D, Tnew = decompose_udt(U)
+    T = Tnew @ T
+    return U, D, T
+
+
+# test/testfunctions.jl:80-118: G(slice) = [1 + B(slice)...B(1) B(M)...B(slice+1)]^-1
+def calculate_greens_and_logdet(B, M, slice_, safe_mult):
+    n = B(1).shape[0]
+    if slice_ + 1 <= M:
+        Ur, Dr, Tr = slice_matrix_chain_dagger(B, slice_ + 1, M, safe_mult)
+    else:
+        Ur, Dr, Tr = np.eye(n), np.ones(n), np.eye(n)
+    if slice_ >= 1:
+        Ul, Dl, Tl = slice_matrix_chain(B, 1, slice_, safe_mult)
+    else:
+        Ul, Dl, Tl = np.eye(n), np.ones(n), np.eye(n)
+    tmp = Tl @ Tr.T
+    U, D, T = decompose_udt(Dl[:, None] * tmp * Dr[None, :])
+    U = Ul @ U
+    T = T @ Ur.T
+    u, d, t = decompose_udt(U.T @ np.linalg.inv(T) + np.diag(D))
+    T = np.linalg.inv(t @ T)
+    U = (U @ u).T
+    d = 1.0 / d
+    return T @ np.diag(d) @ U
+
+
+# --------------------------------------------------------------------------
+# Exact diagonalisation, test/ED/ED.jl
+def _fermion_ops(n_modes):
+    """Jordan-Wigner annihilators c_0..c_{n-1} on the 2^n Fock space."""
+    I2 = np.eye(2); Z = np.diag([1.0, -1.0]); a = np.array([[0.0, 1.0], [0.0, 0.0]])
+    ops = []
+    for m in range(n_modes):
+        mats = [Z] * m + [a] + [I2] * (n_modes - m - 1)
+        M = mats[0]
+        for x in mats[1:]:
+            M = np.kron(M, x)
+        ops.append(M)
+    return ops
+
+
+def ed_hubbard_greens(neighs, n_sites, U, t, mu, beta):
+    """G[(s1,i),(s2,j)] = <c_{i,s1} c^dagger_{j,s2}> for
+    H = -t sum_{src, trg in neighs[:,src], sigma} c^dag_{trg} c_{src}
+        + U sum_i (n_up-1/2)(n_dn-1/2) - mu sum_i n_i      (ED.jl:68-120);
+    U < 0 for the attractive model.  neighs is 4 x N, 1-based.  Mode index =
+    n_sites*substate + site as in calculate_Greens_matrix (ED.jl:497-518)."""
+    nm = 2 * n_sites
+    c = _fermion_ops(nm)
+    cd = [x.T for x in c]
+    H = np.zeros((2 ** nm, 2 ** nm))
+    for s in range(2):
+        for src in range(n_sites):
+            for trg in neighs[:, src] - 1:
+                H -= t * cd[n_sites * s + trg] @ c[n_sites * s + src]
+    Id = np.eye(2 ** nm)
+    for i in range(n_sites):
+        nu = cd[i] @ c[i]
+        nd = cd[n_sites + i] @ c[n_sites + i]
+        H += U * (nu - 0.5 * Id) @ (nd - 0.5 * Id) - mu * (nu + nd)
+    w, V = np.linalg.eigh(H)
+    w = w - w.min()
+    rho = (V * np.exp(-beta * w)) @ V.T
+    Z = np.trace(rho)
+    G = np.zeros((nm, nm))
+    for a_ in range(nm):
+        for b_ in range(nm):
+            G[a_, b_] = np.trace(rho @ c[a_] @ cd[b_]) / Z
+    return G
