@@ -1,0 +1,188 @@
+/*
+ * dqmc_hip.h — C ABI of libdqmc_hip.so, the MI355X (gfx950) DQMC sweep engine.
+ *
+ * The reference (ffreyer/MonteCarlo.jl) has no FFI: its plugin surface is Julia
+ * dispatch on `Stack <: AbstractDQMCStack` (src/flavors/DQMC/DQMC.jl:133-136,
+ * stack.jl:108,242).  This ABI is what a `HIPDQMCStack <: AbstractDQMCStack`
+ * would `ccall` (binding text in INTEGRATION.md).  Every entry point names the
+ * reference function/state it stands in for.  All paths are relative to the
+ * reference repository root.
+ *
+ * Conventions
+ *  - every function returns 0 on success or a negative dqmc_status; the message
+ *    is available from dqmc_last_error().  No C++ exception crosses the ABI.
+ *  - matrices are IEEE fp64, column-major, exactly as Julia `Matrix{Float64}`;
+ *    the HS field is `Array{Int8,2}` (n_sites x slices, column-major, values ±1);
+ *    pivots are Int64 and 1-based as in Julia.
+ *  - the caller owns every host buffer; the library owns all device memory.
+ *  - numerical events (propagation instability, negative determinant ratio) are
+ *    counters, not errors, as in the reference (DQMC.jl:4-47).
+ *  - a handle drives one device from one host thread.
+ *  - "unit" = (walker, block): attractive model 1 block per walker, repulsive
+ *    model 2 blocks (spin up / down, src/linalg/blockdiagonal.jl:13-36).  Buffers
+ *    documented as "per walker" hold n_blocks consecutive n x n matrices.
+ */
+#ifndef DQMC_HIP_H
+#define DQMC_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dqmc_handle dqmc_handle;
+
+typedef enum {
+    DQMC_OK = 0,
+    DQMC_ERR_INVALID = -1,  /* bad argument (Julia: error()/@assert, e.g. stack.jl:173) */
+    DQMC_ERR_HIP = -2,      /* HIP runtime error */
+    DQMC_ERR_NO_DEVICE = -3,
+    DQMC_ERR_STATE = -4,    /* call order violated (e.g. sweep before prepare) */
+    DQMC_ERR_RNG = -5       /* host-supplied uniform stream exhausted */
+} dqmc_status;
+
+enum { DQMC_ATTRACTIVE = 0, DQMC_REPULSIVE = 1 };
+
+/* DQMCParameters (DQMC.jl:52-125) + the model fields the hot path reads
+ * (HubbardModelAttractive.jl:26-39, HubbardModelRepulsive.jl:24-41) + the
+ * host-computed hopping exponentials (stack.jl:167-181). */
+typedef struct {
+    int32_t n_sites;                 /* length(lattice) */
+    int32_t model_kind;              /* DQMC_ATTRACTIVE / DQMC_REPULSIVE */
+    int32_t slices;                  /* mc.p.slices, must be divisible by safe_mult (stack.jl:115) */
+    int32_t safe_mult;               /* mc.p.safe_mult */
+    int32_t n_walkers;               /* independent Markov chains batched on this device */
+    int32_t device_id;
+    int32_t check_propagation_error; /* mc.p.check_propagation_error */
+    int32_t check_sign_problem;      /* mc.p.check_sign_problem */
+    double delta_tau;                /* mc.p.delta_tau */
+    double U;                        /* model.U (>= 0, sign carried by model_kind) */
+    /* n_blocks consecutive n x n col-major matrices each; copied at create */
+    const double *eT;                /* hopping_matrix_exp             = exp(-dtau/2 T) */
+    const double *eTinv;             /* hopping_matrix_exp_inv         = exp(+dtau/2 T) */
+    const double *eT2;               /* hopping_matrix_exp_squared     */
+    const double *eTinv2;            /* hopping_matrix_exp_inv_squared */
+} dqmc_params;
+
+/* MagnitudeStats (DQMC.jl:4-31): log10 magnitudes */
+typedef struct {
+    double max, min, sum;
+    int64_t count;
+} dqmc_magstats;
+
+/* DQMCAnalysis (DQMC.jl:36-47) for one walker */
+typedef struct {
+    int64_t prop_local, acc_local;
+    dqmc_magstats imaginary_probability; /* always empty: the Hubbard models are real (HubbardModel.jl:52) */
+    dqmc_magstats negative_probability;
+    dqmc_magstats propagation_error;
+} dqmc_stats;
+
+/* ---- lifetime ---------------------------------------------------------- */
+/* DQMC(model; ...) + init!(mc) + initialize_stack (DQMC.jl:250-289,337-341; stack.jl:108-159) */
+int dqmc_create(const dqmc_params *p, dqmc_handle **out);
+int dqmc_destroy(dqmc_handle *h);
+/* message of the last failing call on this handle (h may be NULL: create errors) */
+const char *dqmc_last_error(const dqmc_handle *h);
+/* number of visible HIP devices (0 if none); never fails */
+int dqmc_device_count(void);
+
+/* ---- state ------------------------------------------------------------- */
+/* mc.conf (HubbardModel.jl:4-5,46-48); conf is n_sites x slices Int8 */
+int dqmc_set_conf(dqmc_handle *h, int32_t walker, const int8_t *conf);
+int dqmc_get_conf(dqmc_handle *h, int32_t walker, int8_t *conf);
+/* RNG feeding `rand() < p` (DQMC.jl:573).  Test mode: a host-supplied uniform
+ * stream consumed with the reference's conditional rule (only when p <= 1). */
+int dqmc_set_uniforms(dqmc_handle *h, int32_t walker, const double *u, size_t n);
+/* Production mode: Philox4x32-10 counter stream, counter = draw index, key = seed */
+int dqmc_seed(dqmc_handle *h, int32_t walker, uint64_t seed);
+/* number of uniforms consumed so far by a walker */
+int dqmc_uniforms_used(dqmc_handle *h, int32_t walker, uint64_t *used);
+/* mc.s.current_slice, mc.s.direction (stack.jl:30-31); identical for all walkers */
+int dqmc_get_state(dqmc_handle *h, int32_t *current_slice, int32_t *direction);
+
+/* ---- the sweep loop ---------------------------------------------------- */
+/* init!, build_stack, propagate (DQMC.jl:412-414) */
+int dqmc_prepare(dqmc_handle *h);
+/* build_stack only (stack.jl:242-255) */
+int dqmc_build_stack(dqmc_handle *h);
+/* propagate(mc) (stack.jl:502-631) */
+int dqmc_propagate(dqmc_handle *h);
+/* sweep_spatial(mc) (DQMC.jl:546-582) with propose_local / accept_local!
+ * (HubbardModelAttractive.jl:113-155, HubbardModelRepulsive.jl:128-232) */
+int dqmc_sweep_spatial(dqmc_handle *h);
+/* update(mc, i) = propagate + sweep_spatial (DQMC.jl:523-538) */
+int dqmc_update(dqmc_handle *h);
+/* n_sweeps x (2*slices x update), the loop body of run! (DQMC.jl:420-437)
+ * without measurements.  Asynchronous work is complete on return. */
+int dqmc_sweep(dqmc_handle *h, int32_t n_sweeps);
+/* updates until current_slice == 1 && direction == +1 — the measurement point
+ * of run! (DQMC.jl:425-436); *n_updates receives the number of updates run */
+int dqmc_update_until_measure(dqmc_handle *h, int32_t *n_updates);
+/* wait for all queued device work of this handle */
+int dqmc_synchronize(dqmc_handle *h);
+
+/* ---- Green's functions -------------------------------------------------- */
+/* mc.s.greens: effective G at current_slice, n_blocks x (n x n) */
+int dqmc_get_greens_eff(dqmc_handle *h, int32_t walker, double *out);
+int dqmc_set_greens_eff(dqmc_handle *h, int32_t walker, const double *in);
+/* greens(mc) = eTinv * mc.s.greens * eT (DQMC.jl:721-730) */
+int dqmc_get_greens(dqmc_handle *h, int32_t walker, double *out);
+/* calculate_greens(mc, slice) from scratch (stack.jl:422-480); runs for all
+ * walkers, returns the chosen walker's G.  Overwrites Ul..Tr, curr_U, tmp1/2
+ * like the reference; does not touch mc.s.greens or the stack slots. */
+int dqmc_calculate_greens_at(dqmc_handle *h, int32_t walker, int32_t slice, double *out);
+/* wrap_greens!(mc, mc.s.greens, slice, direction) on all walkers (stack.jl:491-500) */
+int dqmc_wrap_greens(dqmc_handle *h, int32_t slice, int32_t direction);
+
+/* ---- analysis ----------------------------------------------------------- */
+int dqmc_get_stats(dqmc_handle *h, int32_t walker, dqmc_stats *out);
+
+/* ---- measurement accumulators (stand-in for push!(LogBinner, greens(mc)),
+ * measurements/generic.jl:207-215,260-263).  dqmc_accumulate_greens adds, for
+ * every walker of this handle, the true G, G.^2 and the occupation 1-G_ii into
+ * device-side sums.  Layout of the accumulator (doubles):
+ *   [0 .. B*n*n)            sum G          (B = n_blocks)
+ *   [B*n*n .. 2*B*n*n)      sum G.^2
+ *   [2*B*n*n .. +B*n)       sum (1 - G_ii)
+ *   last                    number of samples                                 */
+int dqmc_accumulate_greens(dqmc_handle *h);
+int dqmc_accumulator_size(dqmc_handle *h, size_t *n_doubles);
+int dqmc_reset_accumulators(dqmc_handle *h);
+/* copy accumulators to a host buffer, or device-to-device into a caller-owned
+ * device buffer (e.g. a torch tensor that is then all-reduced over RCCL) */
+int dqmc_get_accumulators(dqmc_handle *h, double *host_out);
+int dqmc_export_accumulators(dqmc_handle *h, void *device_out);
+
+/* ---- batched linalg primitives (unit parity with test/slice_matrices.jl) --
+ * host in / host out, `batch` independent n x n problems, run on device_id.  */
+/* vmul! family (src/linalg/general.jl:7-56): C = op(A)*op(B); transa/transb 0|1 */
+int dqmc_vmul(int32_t device_id, int32_t n, int32_t batch, int32_t transa, int32_t transb,
+              const double *A, const double *B, double *C);
+/* udt_AVX_pivot!(U, D, T, pivot, temp, Val(apply)) (src/linalg/UDT.jl:192-306);
+ * T holds the input on entry and T on exit */
+int dqmc_udt_pivot(int32_t device_id, int32_t n, int32_t batch, double *U, double *D, double *T,
+                   int64_t *pivot, int32_t apply_pivot);
+/* rdivp!(A, T, O, pivot) (src/linalg/general.jl:138-166) */
+int dqmc_rdivp(int32_t device_id, int32_t n, int32_t batch, double *A, const double *T,
+               const int64_t *pivot);
+/* calculate_greens_AVX! (src/flavors/DQMC/stack.jl:337-393) */
+int dqmc_calculate_greens(int32_t device_id, int32_t n, int32_t batch, const double *Ul,
+                          const double *Dl, const double *Tl, const double *Ur, const double *Dr,
+                          const double *Tr, double *G);
+
+/* ---- instrumentation ------------------------------------------------------ */
+/* Per-kernel-family device time accumulated with HIP events on the handle's
+ * stream when enabled (off by default; used by bench.py's roofline leg). */
+enum { DQMC_K_GEMM = 0, DQMC_K_QR = 1, DQMC_K_TRSM = 2, DQMC_K_SWEEP = 3, DQMC_K_MISC = 4, DQMC_K_COUNT = 5 };
+int dqmc_timing_enable(dqmc_handle *h, int32_t on);
+int dqmc_timing_get(dqmc_handle *h, double *ms /* DQMC_K_COUNT */, int64_t *launches /* DQMC_K_COUNT */);
+/* fp64 MFMA micro-benchmark: issues `iters` dependent-free v_mfma_f64_16x16x4_f64
+ * per wave on every CU, returns achieved TFLOP/s (confirms the roofline peak) */
+int dqmc_mfma_f64_peak(int32_t device_id, int32_t iters, double *tflops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

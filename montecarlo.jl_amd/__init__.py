@@ -1,0 +1,14 @@
+"""montecarlo.jl_amd — MI355X-native DQMC sweep engine behind the plugin surface of
+ffreyer/MonteCarlo.jl's DQMC flavor (src/flavors/DQMC + src/linalg).
+
+Python here is host plumbing only: lattice/model construction, loop control and the
+ctypes binding of libdqmc_hip.so.  All numerics run in hand-written gfx950 kernels;
+there is no CPU fallback (importing without the built library raises)."""
+from ._lib import DQMCError, lib  # noqa: F401
+from .lattices import Chain, SquareLattice, build_checkerboard  # noqa: F401
+from .models import (HubbardModel, HubbardModelAttractive, HubbardModelRepulsive,  # noqa: F401
+                     rand_conf)
+from .dqmc import (DQMC, DQMCParameters, calculate_greens_AVX, device_count,  # noqa: F401
+                   hopping_exponentials, mfma_f64_peak, rdivp, udt_AVX_pivot, vmul)
+
+lib()  # fail loudly at import time if the HIP library has not been built

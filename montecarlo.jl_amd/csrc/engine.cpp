@@ -1,0 +1,1072 @@
+// engine.cpp — host side of libdqmc_hip.so: device state of a batch of walkers, the
+// propagate state machine of src/flavors/DQMC/stack.jl:502-631 expressed as batched
+// kernel launches on one HIP stream, and the C ABI of include/dqmc_hip.h.
+//
+// All walkers of a handle move in lockstep (same current_slice / direction), so the
+// control flow lives on the host and is identical to the reference's; the data of all
+// walkers is processed by every launch (grid = units x tiles).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/dqmc_hip.h"
+#include "kernels.h"
+
+using namespace dqmc;
+
+static thread_local std::string g_create_error;
+
+struct dqmc_handle {
+    dqmc_params p{};
+    int n = 0, nb = 1, N = 0, M = 0, s = 0, K = 0, W = 0, units = 0, kd = 32;
+    long nn = 0;
+    double lambda = 0, epl = 0, eml = 0;
+    SweepConsts sc{};
+    hipStream_t stream = nullptr;
+    // constants (nb x n x n)
+    double *eT = nullptr, *eTinv = nullptr, *eT2 = nullptr, *eTinv2 = nullptr;
+    int8_t *conf = nullptr;  // W x (N x M)
+    // stack (slot-major): u/t: (K+1) x units x n^2 ; d: (K+1) x units x n
+    double *u_stack = nullptr, *t_stack = nullptr, *d_stack = nullptr;
+    double *Ul = nullptr, *Ur = nullptr, *Tl = nullptr, *Tr = nullptr, *greens = nullptr, *greens_temp = nullptr;
+    double *tmp1 = nullptr, *tmp2 = nullptr, *bufA = nullptr, *bufB = nullptr;
+    double *qrV = nullptr, *qrW = nullptr, *qrS = nullptr;
+    double *Dl = nullptr, *Dr = nullptr, *tau = nullptr;
+    int *pivot = nullptr;
+    double *sU = nullptr, *sVT = nullptr;
+    WalkerRng *rng = nullptr;
+    DevStats *stats = nullptr;
+    std::vector<double *> uniforms;  // per walker device arrays
+    double *acc = nullptr;
+    size_t acc_n = 0;
+    int current_slice = 0, direction = 0;
+    bool prepared = false;
+    std::string err;
+    // timing
+    bool timing = false;
+    struct Ev { hipEvent_t a, b; int fam; };
+    std::vector<Ev> pending;
+    std::vector<hipEvent_t> pool;
+    double fam_ms[DQMC_K_COUNT] = {0};
+    long long fam_n[DQMC_K_COUNT] = {0};
+    std::vector<void *> allocs;
+};
+
+// ---------------------------------------------------------------------------
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            h->err = std::string(#expr) + ": " + hipGetErrorString(e_);                                \
+            return DQMC_ERR_HIP;                                                                       \
+        }                                                                                              \
+    } while (0)
+#define CHK(expr)                \
+    do {                         \
+        int rc_ = (expr);        \
+        if (rc_ != 0) return rc_; \
+    } while (0)
+
+static int fail(dqmc_handle *h, int code, const std::string &msg)
+{
+    if (h) h->err = msg;
+    else g_create_error = msg;
+    return code;
+}
+
+template <typename T>
+static int dalloc(dqmc_handle *h, T **p, size_t count, bool zero = true)
+{
+    void *q = nullptr;
+    HIPCHK(hipMalloc(&q, (count ? count : 1) * sizeof(T)));
+    h->allocs.push_back(q);
+    if (zero) HIPCHK(hipMemsetAsync(q, 0, (count ? count : 1) * sizeof(T), h->stream));
+    *p = (T *)q;
+    return 0;
+}
+
+// ---- timing scopes ---------------------------------------------------------
+static int timing_drain(dqmc_handle *h)
+{
+    if (h->pending.empty()) return 0;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (auto &e : h->pending) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, e.a, e.b));
+        h->fam_ms[e.fam] += ms;
+        h->fam_n[e.fam] += 1;
+        h->pool.push_back(e.a);
+        h->pool.push_back(e.b);
+    }
+    h->pending.clear();
+    return 0;
+}
+struct Timed {
+    dqmc_handle *h;
+    int fam;
+    hipEvent_t a = nullptr, b = nullptr;
+    Timed(dqmc_handle *h_, int fam_) : h(h_), fam(fam_)
+    {
+        if (!h->timing) return;
+        auto get = [&]() {
+            hipEvent_t e;
+            if (!h->pool.empty()) { e = h->pool.back(); h->pool.pop_back(); }
+            else (void)hipEventCreate(&e);
+            return e;
+        };
+        a = get();
+        b = get();
+        (void)hipEventRecord(a, h->stream);
+    }
+    ~Timed()
+    {
+        if (!h->timing) return;
+        (void)hipEventRecord(b, h->stream);
+        h->pending.push_back({a, b, fam});
+        if (h->pending.size() >= 2048) (void)timing_drain(h);
+    }
+};
+
+// ---- argument builders -------------------------------------------------------
+static GemmArgs gemm_base(dqmc_handle *h, MatRef A, int tA, MatRef B, int tB, double *C)
+{
+    GemmArgs g{};
+    g.M = g.N = g.K = h->n;
+    g.n_units = h->units;
+    g.nb = h->nb;
+    g.A = A;
+    g.B = B;
+    g.C = C;
+    g.strideC = h->nn;
+    g.ldc = h->n;
+    g.transA = tA;
+    g.transB = tB;
+    g.kscale = g.colscale = g.rowscale = g.adddiag = vs_none();
+    g.row_first = 0;
+    g.alpha = 1.0;
+    g.ident = 0.0;
+    g.beta = 0;
+    return g;
+}
+static MatRef U_(dqmc_handle *h, const double *p) { return mat(p, h->nn, h->n); }        // per unit
+static MatRef C_(dqmc_handle *h, const double *p) { return mat(p, 0, h->n, h->nn); }     // shared constant, per block
+static int run_gemm(dqmc_handle *h, const GemmArgs &g)
+{
+    Timed t(h, DQMC_K_GEMM);
+    HIPCHK(launch_gemm(g, h->stream));
+    return 0;
+}
+// exp(sign*lambda*conf[:,slice]) for block 0, exp(-sign*lambda*conf) for block 1
+// (HubbardModelAttractive.jl:100-110, HubbardModelRepulsive.jl:113-126); slice 1-based
+static VecSrc vs_conf(dqmc_handle *h, int slice, int sign)
+{
+    VecSrc v{};
+    v.mode = 2;
+    v.conf = h->conf + (long)(slice - 1) * h->N;
+    v.conf_stride = (long)h->N * h->M;
+    const double a = sign > 0 ? h->epl : h->eml, b = sign > 0 ? h->eml : h->epl;
+    v.cpos[0] = a; v.cneg[0] = b;
+    v.cpos[1] = b; v.cneg[1] = a;
+    return v;
+}
+static double *uslot(dqmc_handle *h, int i) { return h->u_stack + (long)i * h->units * h->nn; }
+static double *tslot(dqmc_handle *h, int i) { return h->t_stack + (long)i * h->units * h->nn; }
+static double *dslot(dqmc_handle *h, int i) { return h->d_stack + (long)i * h->units * h->n; }
+
+static int copy_mat(dqmc_handle *h, double *dst, const double *src)
+{
+    Timed t(h, DQMC_K_MISC);
+    HIPCHK(hipMemcpyAsync(dst, src, sizeof(double) * h->units * h->nn, hipMemcpyDeviceToDevice, h->stream));
+    return 0;
+}
+static int copy_vec(dqmc_handle *h, double *dst, const double *src)
+{
+    Timed t(h, DQMC_K_MISC);
+    HIPCHK(hipMemcpyAsync(dst, src, sizeof(double) * h->units * h->n, hipMemcpyDeviceToDevice, h->stream));
+    return 0;
+}
+static int set_identity(dqmc_handle *h, double *A)
+{
+    Timed t(h, DQMC_K_MISC);
+    HIPCHK(launch_set_identity(h->n, h->units, A, h->nn, h->stream));
+    return 0;
+}
+static int set_ones(dqmc_handle *h, double *d)
+{
+    Timed t(h, DQMC_K_MISC);
+    HIPCHK(launch_fill(d, (size_t)h->units * h->n, 1.0, h->stream));
+    return 0;
+}
+
+// ---- UDT (udt_AVX_pivot!, src/linalg/UDT.jl:192-306) ---------------------------
+// A is factored in place.  Q is formed in compact-WY form with GEMMs instead of the
+// reference's reflector-by-reflector back accumulation (UDT.jl:250-266):
+//   Q = H_1...H_n = I - V S^-1 V',  S = striu(V'V) + diag(1/tau)
+static int udt(dqmc_handle *h, double *A, double *Uout, double *Dout, double *Tout, int apply)
+{
+    const int n = h->n;
+    {
+        Timed t(h, DQMC_K_QR);
+        HIPCHK(launch_qr_pivot(n, h->units, A, h->nn, h->tau, h->pivot, h->stream));
+    }
+    {
+        Timed t(h, DQMC_K_MISC);
+        HIPCHK(launch_udt_finish(n, h->units, A, h->nn, h->pivot, Dout, n, h->qrV, h->nn, Tout, h->nn, apply,
+                                 h->stream));
+    }
+    GemmArgs g = gemm_base(h, U_(h, h->qrV), 1, U_(h, h->qrV), 0, h->qrS);
+    CHK(run_gemm(h, g));
+    {
+        Timed t(h, DQMC_K_TRSM);
+        HIPCHK(launch_trsm_right_upper(n, h->units, h->qrV, h->nn, h->qrS, h->nn, nullptr, h->tau, n, h->qrW, h->nn,
+                                       h->stream));
+    }
+    g = gemm_base(h, U_(h, h->qrW), 0, U_(h, h->qrV), 1, Uout);
+    g.alpha = -1.0;
+    g.ident = 1.0;
+    CHK(run_gemm(h, g));
+    return 0;
+}
+static int rdivp(dqmc_handle *h, double *A, const double *T)
+{
+    Timed t(h, DQMC_K_TRSM);
+    HIPCHK(launch_trsm_right_upper(h->n, h->units, A, h->nn, T, h->nn, h->pivot, nullptr, 0, A, h->nn, h->stream));
+    return 0;
+}
+
+// ---- calculate_greens_AVX! (stack.jl:337-393) -----------------------------------
+static int calculate_greens(dqmc_handle *h, double *out)
+{
+    const int n = h->n;
+    GemmArgs g = gemm_base(h, U_(h, h->Tl), 0, U_(h, h->Tr), 1, out);  // :346-348
+    g.colscale = vs_arr(h->Dr, n);
+    g.rowscale = vs_arr(h->Dl, n);
+    CHK(run_gemm(h, g));
+    CHK(udt(h, out, h->Tr, h->Dr, nullptr, 0));                        // :349
+    CHK(run_gemm(h, gemm_base(h, U_(h, h->Ul), 0, U_(h, h->Tr), 0, h->Tl)));  // :360
+    CHK(rdivp(h, h->Ur, out));                                         // :361
+    g = gemm_base(h, U_(h, h->Tl), 1, U_(h, h->Ur), 0, h->Tr);         // :362 + :368
+    g.adddiag = vs_arr(h->Dr, n);
+    CHK(run_gemm(h, g));
+    CHK(udt(h, h->Tr, h->Ul, h->Dr, nullptr, 0));                      // :376
+    CHK(rdivp(h, h->Ur, h->Tr));                                       // :377
+    CHK(run_gemm(h, gemm_base(h, U_(h, h->Tl), 0, U_(h, h->Ul), 0, h->Tr)));  // :378
+    g = gemm_base(h, U_(h, h->Ur), 0, U_(h, h->Tr), 1, out);           // :382-391
+    g.kscale = vs_inv(h->Dr, n);
+    CHK(run_gemm(h, g));
+    return 0;
+}
+
+// ---- slice sequences (stack.jl:272-311, slice_matrices.jl:42-76) -------------------
+static int add_slice_sequence_left(dqmc_handle *h, int idx)  // idx 1-based as in the reference
+{
+    const double *X = uslot(h, idx - 1);
+    double *out = nullptr;
+    for (int t = 0; t < h->s; ++t) {
+        const int slice = (idx - 1) * h->s + 1 + t;
+        out = (t & 1) ? h->bufB : h->bufA;
+        GemmArgs g = gemm_base(h, C_(h, h->eT2), 0, U_(h, X), 0, out);
+        g.kscale = vs_conf(h, slice, +1);
+        if (t == h->s - 1) g.colscale = vs_arr(dslot(h, idx - 1), h->n);  // stack.jl:281
+        CHK(run_gemm(h, g));
+        X = out;
+    }
+    CHK(udt(h, out, uslot(h, idx), dslot(h, idx), h->tmp2, 1));
+    CHK(run_gemm(h, gemm_base(h, U_(h, h->tmp2), 0, U_(h, tslot(h, idx - 1)), 0, tslot(h, idx))));
+    return 0;
+}
+static int add_slice_sequence_right(dqmc_handle *h, int idx)
+{
+    const double *X = uslot(h, idx);
+    double *out = nullptr;
+    for (int t = 0; t < h->s; ++t) {
+        const int slice = idx * h->s - t;
+        out = (t & 1) ? h->bufB : h->bufA;
+        GemmArgs g = gemm_base(h, C_(h, h->eT2), 1, U_(h, X), 0, out);  // (eT2*eV)' = eV*eT2'
+        g.rowscale = vs_conf(h, slice, +1);
+        g.row_first = 1;
+        if (t == h->s - 1) g.colscale = vs_arr(dslot(h, idx), h->n);  // stack.jl:305
+        CHK(run_gemm(h, g));
+        X = out;
+    }
+    CHK(udt(h, out, uslot(h, idx - 1), dslot(h, idx - 1), h->tmp2, 1));
+    CHK(run_gemm(h, gemm_base(h, U_(h, h->tmp2), 0, U_(h, tslot(h, idx)), 0, tslot(h, idx - 1))));
+    return 0;
+}
+
+// wrap_greens! (stack.jl:491-500)
+static int wrap_greens(dqmc_handle *h, double *gf, int curr_slice, int direction)
+{
+    if (direction == -1) {
+        const int l = curr_slice - 1;
+        GemmArgs g = gemm_base(h, C_(h, h->eTinv2), 0, U_(h, gf), 0, h->tmp1);  // (eV^-1 eTinv2) * G
+        g.rowscale = vs_conf(h, l, -1);
+        CHK(run_gemm(h, g));
+        g = gemm_base(h, U_(h, h->tmp1), 0, C_(h, h->eT2), 0, gf);              // . * (eT2 eV)
+        g.colscale = vs_conf(h, l, +1);
+        CHK(run_gemm(h, g));
+    } else {
+        const int l = curr_slice;
+        GemmArgs g = gemm_base(h, C_(h, h->eT2), 0, U_(h, gf), 0, h->tmp1);     // (eT2 eV) * G
+        g.kscale = vs_conf(h, l, +1);
+        CHK(run_gemm(h, g));
+        g = gemm_base(h, U_(h, h->tmp1), 0, C_(h, h->eTinv2), 0, gf);           // . * (eV^-1 eTinv2)
+        g.kscale = vs_conf(h, l, -1);
+        CHK(run_gemm(h, g));
+    }
+    return 0;
+}
+
+static int load_slot(dqmc_handle *h, double *U, double *D, double *T, int slot)
+{
+    CHK(copy_mat(h, U, uslot(h, slot)));
+    CHK(copy_vec(h, D, dslot(h, slot)));
+    CHK(copy_mat(h, T, tslot(h, slot)));
+    return 0;
+}
+static int reset_slot(dqmc_handle *h, int slot)
+{
+    CHK(set_identity(h, uslot(h, slot)));
+    CHK(set_ones(h, dslot(h, slot)));
+    CHK(set_identity(h, tslot(h, slot)));
+    return 0;
+}
+static int prop_check(dqmc_handle *h)
+{
+    Timed t(h, DQMC_K_MISC);
+    HIPCHK(launch_prop_check(h->n, h->nb, h->W, h->greens_temp, h->greens, h->nn, h->stats, h->stream));
+    return 0;
+}
+
+// stack.jl:108-159 (the parts with observable effect)
+static int init_stack(dqmc_handle *h)
+{
+    CHK(set_identity(h, h->Ul)); CHK(set_identity(h, h->Ur));
+    CHK(set_identity(h, h->Tl)); CHK(set_identity(h, h->Tr));
+    CHK(set_ones(h, h->Dl)); CHK(set_ones(h, h->Dr));
+    h->current_slice = 0;
+    h->direction = 0;
+    return 0;
+}
+// stack.jl:242-255
+static int build_stack(dqmc_handle *h)
+{
+    CHK(reset_slot(h, 0));
+    for (int i = 1; i <= h->K; ++i) CHK(add_slice_sequence_left(h, i));
+    h->current_slice = h->M + 1;
+    h->direction = -1;
+    return 0;
+}
+
+// stack.jl:502-631
+static int propagate(dqmc_handle *h)
+{
+    const int M = h->M, s = h->s;
+    if (h->direction == 1) {
+        if (h->current_slice % s == 0) {
+            h->current_slice += 1;
+            if (h->current_slice == 1) {
+                CHK(load_slot(h, h->Ur, h->Dr, h->Tr, 0));
+                CHK(reset_slot(h, 0));
+                CHK(load_slot(h, h->Ul, h->Dl, h->Tl, 0));
+                CHK(calculate_greens(h, h->greens));
+            } else if (1 < h->current_slice && h->current_slice <= M) {
+                const int idx = (h->current_slice - 1) / s;
+                CHK(load_slot(h, h->Ur, h->Dr, h->Tr, idx));
+                CHK(add_slice_sequence_left(h, idx));
+                CHK(load_slot(h, h->Ul, h->Dl, h->Tl, idx));
+                if (h->p.check_propagation_error) {
+                    CHK(copy_mat(h, h->greens_temp, h->greens));
+                    // stack.jl:534-536 wraps greens_temp unconditionally; its result is only
+                    // observable through the check, so the wrap is skipped when the check is off
+                    CHK(wrap_greens(h, h->greens_temp, h->current_slice - 1, 1));
+                }
+                CHK(calculate_greens(h, h->greens));
+                if (h->p.check_propagation_error) CHK(prop_check(h));
+            } else {
+                CHK(add_slice_sequence_left(h, h->K));
+                h->direction = -1;
+                h->current_slice = M + 1;
+                CHK(propagate(h));
+            }
+        } else {
+            CHK(wrap_greens(h, h->greens, h->current_slice, 1));
+            h->current_slice += 1;
+        }
+    } else {
+        if ((h->current_slice - 1) % s == 0) {
+            h->current_slice -= 1;
+            if (h->current_slice == M) {
+                CHK(load_slot(h, h->Ul, h->Dl, h->Tl, h->K));
+                CHK(reset_slot(h, h->K));
+                CHK(load_slot(h, h->Ur, h->Dr, h->Tr, h->K));
+                CHK(calculate_greens(h, h->greens));
+                CHK(wrap_greens(h, h->greens, h->current_slice + 1, -1));
+            } else if (0 < h->current_slice && h->current_slice < M) {
+                const int idx = h->current_slice / s + 1;
+                CHK(load_slot(h, h->Ul, h->Dl, h->Tl, idx - 1));
+                CHK(add_slice_sequence_right(h, idx));
+                CHK(load_slot(h, h->Ur, h->Dr, h->Tr, idx - 1));
+                if (h->p.check_propagation_error) CHK(copy_mat(h, h->greens_temp, h->greens));
+                CHK(calculate_greens(h, h->greens));
+                if (h->p.check_propagation_error) CHK(prop_check(h));
+                CHK(wrap_greens(h, h->greens, h->current_slice + 1, -1));
+            } else {
+                CHK(add_slice_sequence_right(h, 1));
+                h->direction = 1;
+                h->current_slice = 0;
+                CHK(propagate(h));
+            }
+        } else {
+            CHK(wrap_greens(h, h->greens, h->current_slice, -1));
+            h->current_slice -= 1;
+        }
+    }
+    return 0;
+}
+
+// DQMC.jl:546-582
+static int sweep_spatial(dqmc_handle *h)
+{
+    const int l = h->current_slice;
+    if (l < 1 || l > h->M) return fail(h, DQMC_ERR_STATE, "sweep_spatial: current_slice outside 1..slices");
+    int8_t *cslice = h->conf + (long)(l - 1) * h->N;
+    for (int site0 = 0; site0 < h->N; site0 += h->kd) {
+        const int ns = std::min(h->kd, h->N - site0);
+        {
+            Timed t(h, DQMC_K_SWEEP);
+            HIPCHK(launch_sweep_chunk(h->n, h->nb, h->W, h->p.model_kind, h->greens, h->nn, cslice, (long)h->N * h->M,
+                                      site0, ns, h->sU, h->sVT, (long)h->n * h->kd, h->sc, h->rng, h->stats,
+                                      h->p.check_sign_problem, h->stream));
+        }
+        GemmArgs g = gemm_base(h, mat(h->sU, (long)h->n * h->kd, h->n), 0, mat(h->sVT, (long)h->n * h->kd, h->n), 1,
+                               h->greens);
+        g.K = h->kd;
+        g.beta = 1;
+        CHK(run_gemm(h, g));
+    }
+    return 0;
+}
+
+// ===========================================================================
+// C ABI
+// ===========================================================================
+extern "C" {
+
+const char *dqmc_last_error(const dqmc_handle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int dqmc_device_count(void)
+{
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) return 0;
+    return c;
+}
+
+int dqmc_create(const dqmc_params *p, dqmc_handle **out)
+{
+    if (!p || !out) return fail(nullptr, DQMC_ERR_INVALID, "dqmc_create: null argument");
+    *out = nullptr;
+    if (p->n_sites < 1 || p->slices < 1 || p->safe_mult < 1 || p->n_walkers < 1)
+        return fail(nullptr, DQMC_ERR_INVALID, "dqmc_create: n_sites, slices, safe_mult, n_walkers must be >= 1");
+    if (p->slices % p->safe_mult != 0)  // stack.jl:115: convert(Int, slices / safe_mult) throws InexactError
+        return fail(nullptr, DQMC_ERR_INVALID, "dqmc_create: slices must be divisible by safe_mult");
+    if (p->model_kind != DQMC_ATTRACTIVE && p->model_kind != DQMC_REPULSIVE)
+        return fail(nullptr, DQMC_ERR_INVALID, "dqmc_create: unknown model_kind");
+    if (!p->eT || !p->eTinv || !p->eT2 || !p->eTinv2)
+        return fail(nullptr, DQMC_ERR_INVALID, "dqmc_create: hopping exponentials missing");
+    if (!(p->U >= 0.0)) return fail(nullptr, DQMC_ERR_INVALID, "dqmc_create: U must be positive");
+    const int nb = p->model_kind == DQMC_REPULSIVE ? 2 : 1;
+    if (nb * ((p->n_sites + 63) & ~63) > 1024 || p->n_sites > 1024)
+        return fail(nullptr, DQMC_ERR_INVALID, "dqmc_create: n_blocks * n_sites exceeds 1024 (unsupported)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(nullptr, DQMC_ERR_NO_DEVICE, "dqmc_create: no HIP device visible");
+    if (p->device_id < 0 || p->device_id >= ndev)
+        return fail(nullptr, DQMC_ERR_INVALID, "dqmc_create: device_id out of range");
+
+    dqmc_handle *h = new dqmc_handle();
+    h->p = *p;
+    h->p.eT = h->p.eTinv = h->p.eT2 = h->p.eTinv2 = nullptr;
+    h->N = h->n = p->n_sites;
+    h->nb = nb;
+    h->M = p->slices;
+    h->s = p->safe_mult;
+    h->K = h->M / h->s;
+    h->W = p->n_walkers;
+    h->units = h->W * h->nb;
+    h->nn = (long)h->n * h->n;
+    h->kd = sweep_kd(h->n, h->nb);
+    // lambda = acosh(exp(U*dtau/2)) (Attractive.jl:103,118; Repulsive.jl:116,138)
+    h->lambda = std::acosh(std::exp(0.5 * p->U * p->delta_tau));
+    h->epl = std::exp(h->lambda);
+    h->eml = std::exp(-h->lambda);
+    for (int ci = 0; ci < 2; ++ci) {
+        const double c = ci ? 1.0 : -1.0;
+        const double dE = -2.0 * h->lambda * c;
+        h->sc.gamma[ci] = std::exp(dE) - 1.0;
+        h->sc.ebos[ci] = std::exp(-dE);
+        h->sc.dup[ci] = std::exp(dE) - 1.0;
+        h->sc.ddn[ci] = std::exp(-dE) - 1.0;
+    }
+    auto bail = [&](int rc) {
+        g_create_error = h->err;
+        dqmc_destroy(h);
+        return rc;
+    };
+#define CCHK(expr)                     \
+    do {                               \
+        int rc__ = (expr);             \
+        if (rc__ != 0) return bail(rc__); \
+    } while (0)
+#define CHIP(expr)                                                        \
+    do {                                                                  \
+        hipError_t e__ = (expr);                                          \
+        if (e__ != hipSuccess) {                                          \
+            h->err = std::string(#expr) + ": " + hipGetErrorString(e__);  \
+            return bail(DQMC_ERR_HIP);                                    \
+        }                                                                 \
+    } while (0)
+    CHIP(hipSetDevice(p->device_id));
+    CHIP(hipStreamCreate(&h->stream));
+    const size_t cn = (size_t)nb * h->nn, un = (size_t)h->units * h->nn, uv = (size_t)h->units * h->n;
+    CCHK(dalloc(h, &h->eT, cn)); CCHK(dalloc(h, &h->eTinv, cn));
+    CCHK(dalloc(h, &h->eT2, cn)); CCHK(dalloc(h, &h->eTinv2, cn));
+    CHIP(hipMemcpy(h->eT, p->eT, cn * sizeof(double), hipMemcpyHostToDevice));
+    CHIP(hipMemcpy(h->eTinv, p->eTinv, cn * sizeof(double), hipMemcpyHostToDevice));
+    CHIP(hipMemcpy(h->eT2, p->eT2, cn * sizeof(double), hipMemcpyHostToDevice));
+    CHIP(hipMemcpy(h->eTinv2, p->eTinv2, cn * sizeof(double), hipMemcpyHostToDevice));
+    CCHK(dalloc(h, &h->conf, (size_t)h->W * h->N * h->M));
+    {
+        std::vector<int8_t> ones((size_t)h->W * h->N * h->M, 1);
+        CHIP(hipMemcpy(h->conf, ones.data(), ones.size(), hipMemcpyHostToDevice));
+    }
+    CCHK(dalloc(h, &h->u_stack, (size_t)(h->K + 1) * un));
+    CCHK(dalloc(h, &h->t_stack, (size_t)(h->K + 1) * un));
+    CCHK(dalloc(h, &h->d_stack, (size_t)(h->K + 1) * uv));
+    double **mats[] = {&h->Ul, &h->Ur, &h->Tl, &h->Tr, &h->greens, &h->greens_temp, &h->tmp1,
+                       &h->tmp2, &h->bufA, &h->bufB, &h->qrV, &h->qrW, &h->qrS};
+    for (auto m : mats) CCHK(dalloc(h, m, un));
+    CCHK(dalloc(h, &h->Dl, uv)); CCHK(dalloc(h, &h->Dr, uv)); CCHK(dalloc(h, &h->tau, uv));
+    CCHK(dalloc(h, &h->pivot, uv));
+    CCHK(dalloc(h, &h->sU, (size_t)h->units * h->n * h->kd));
+    CCHK(dalloc(h, &h->sVT, (size_t)h->units * h->n * h->kd));
+    CCHK(dalloc(h, &h->rng, (size_t)h->W));
+    CCHK(dalloc(h, &h->stats, (size_t)h->W));
+    {
+        std::vector<DevStats> st(h->W);
+        for (auto &x : st) {
+            x.prop_local = x.acc_local = 0;
+            x.negative_probability = {-INFINITY, INFINITY, 0.0, 0};
+            x.propagation_error = {-INFINITY, INFINITY, 0.0, 0};
+        }
+        CHIP(hipMemcpy(h->stats, st.data(), sizeof(DevStats) * h->W, hipMemcpyHostToDevice));
+        std::vector<WalkerRng> rg(h->W);
+        for (int w = 0; w < h->W; ++w) rg[w] = {(unsigned long long)w, 0ull, nullptr, 0ull, 0};
+        CHIP(hipMemcpy(h->rng, rg.data(), sizeof(WalkerRng) * h->W, hipMemcpyHostToDevice));
+    }
+    h->uniforms.assign(h->W, nullptr);
+    h->acc_n = 2 * cn + (size_t)nb * h->n + 1;
+    CCHK(dalloc(h, &h->acc, h->acc_n));
+    CCHK(init_stack(h));
+    CHIP(hipStreamSynchronize(h->stream));
+#undef CCHK
+#undef CHIP
+    *out = h;
+    return DQMC_OK;
+}
+
+int dqmc_destroy(dqmc_handle *h)
+{
+    if (!h) return DQMC_OK;
+    (void)hipSetDevice(h->p.device_id);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (auto &e : h->pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (auto e : h->pool) (void)hipEventDestroy(e);
+    for (void *q : h->allocs) (void)hipFree(q);
+    for (double *u : h->uniforms)
+        if (u) (void)hipFree(u);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return DQMC_OK;
+}
+
+#define ENTER(h)                                                        \
+    if (!(h)) return DQMC_ERR_INVALID;                                  \
+    HIPCHK(hipSetDevice((h)->p.device_id))
+#define WALKER_OK(h, w) \
+    if ((w) < 0 || (w) >= (h)->W) return fail((h), DQMC_ERR_INVALID, "walker index out of range")
+
+int dqmc_set_conf(dqmc_handle *h, int32_t w, const int8_t *conf)
+{
+    ENTER(h); WALKER_OK(h, w);
+    const size_t sz = (size_t)h->N * h->M;
+    for (size_t i = 0; i < sz; ++i)
+        if (conf[i] != 1 && conf[i] != -1) return fail(h, DQMC_ERR_INVALID, "conf entries must be +1 or -1");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(h->conf + (size_t)w * sz, conf, sz, hipMemcpyHostToDevice));
+    return DQMC_OK;
+}
+int dqmc_get_conf(dqmc_handle *h, int32_t w, int8_t *conf)
+{
+    ENTER(h); WALKER_OK(h, w);
+    const size_t sz = (size_t)h->N * h->M;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(conf, h->conf + (size_t)w * sz, sz, hipMemcpyDeviceToHost));
+    return DQMC_OK;
+}
+int dqmc_set_uniforms(dqmc_handle *h, int32_t w, const double *u, size_t n)
+{
+    ENTER(h); WALKER_OK(h, w);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->uniforms[w]) { HIPCHK(hipFree(h->uniforms[w])); h->uniforms[w] = nullptr; }
+    HIPCHK(hipMalloc((void **)&h->uniforms[w], (n ? n : 1) * sizeof(double)));
+    HIPCHK(hipMemcpy(h->uniforms[w], u, n * sizeof(double), hipMemcpyHostToDevice));
+    WalkerRng r = {0ull, 0ull, h->uniforms[w], (unsigned long long)n, 0};
+    HIPCHK(hipMemcpy(h->rng + w, &r, sizeof(r), hipMemcpyHostToDevice));
+    return DQMC_OK;
+}
+int dqmc_seed(dqmc_handle *h, int32_t w, uint64_t seed)
+{
+    ENTER(h); WALKER_OK(h, w);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    WalkerRng r = {(unsigned long long)seed, 0ull, nullptr, 0ull, 0};
+    HIPCHK(hipMemcpy(h->rng + w, &r, sizeof(r), hipMemcpyHostToDevice));
+    return DQMC_OK;
+}
+int dqmc_uniforms_used(dqmc_handle *h, int32_t w, uint64_t *used)
+{
+    ENTER(h); WALKER_OK(h, w);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    WalkerRng r;
+    HIPCHK(hipMemcpy(&r, h->rng + w, sizeof(r), hipMemcpyDeviceToHost));
+    *used = r.draw;
+    return DQMC_OK;
+}
+int dqmc_get_state(dqmc_handle *h, int32_t *cs, int32_t *dir)
+{
+    if (!h) return DQMC_ERR_INVALID;
+    if (cs) *cs = h->current_slice;
+    if (dir) *dir = h->direction;
+    return DQMC_OK;
+}
+
+static int check_rng(dqmc_handle *h)
+{
+    std::vector<WalkerRng> rg(h->W);
+    HIPCHK(hipMemcpy(rg.data(), h->rng, sizeof(WalkerRng) * h->W, hipMemcpyDeviceToHost));
+    for (int w = 0; w < h->W; ++w)
+        if (rg[w].exhausted) return fail(h, DQMC_ERR_RNG, "host-supplied uniform stream exhausted");
+    return 0;
+}
+int dqmc_synchronize(dqmc_handle *h)
+{
+    ENTER(h);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    CHK(timing_drain(h));
+    return check_rng(h);
+}
+int dqmc_build_stack(dqmc_handle *h)
+{
+    ENTER(h);
+    CHK(build_stack(h));
+    h->prepared = true;
+    return dqmc_synchronize(h);
+}
+int dqmc_prepare(dqmc_handle *h)
+{
+    ENTER(h);
+    CHK(init_stack(h));
+    CHK(build_stack(h));
+    CHK(propagate(h));
+    h->prepared = true;
+    return dqmc_synchronize(h);
+}
+#define NEED_PREPARED(h) \
+    if (!(h)->prepared) return fail((h), DQMC_ERR_STATE, "call dqmc_prepare or dqmc_build_stack first")
+int dqmc_propagate(dqmc_handle *h)
+{
+    ENTER(h); NEED_PREPARED(h);
+    CHK(propagate(h));
+    return dqmc_synchronize(h);
+}
+int dqmc_sweep_spatial(dqmc_handle *h)
+{
+    ENTER(h); NEED_PREPARED(h);
+    CHK(sweep_spatial(h));
+    return dqmc_synchronize(h);
+}
+int dqmc_update(dqmc_handle *h)
+{
+    ENTER(h); NEED_PREPARED(h);
+    CHK(propagate(h));
+    CHK(sweep_spatial(h));
+    return dqmc_synchronize(h);
+}
+int dqmc_sweep(dqmc_handle *h, int32_t n_sweeps)
+{
+    ENTER(h); NEED_PREPARED(h);
+    for (int i = 0; i < n_sweeps; ++i)
+        for (int u = 0; u < 2 * h->M; ++u) {
+            CHK(propagate(h));
+            CHK(sweep_spatial(h));
+        }
+    return dqmc_synchronize(h);
+}
+int dqmc_update_until_measure(dqmc_handle *h, int32_t *n_updates)
+{
+    ENTER(h); NEED_PREPARED(h);
+    int cnt = 0;
+    do {
+        CHK(propagate(h));
+        CHK(sweep_spatial(h));
+        ++cnt;
+    } while (!(h->current_slice == 1 && h->direction == 1));
+    if (n_updates) *n_updates = cnt;
+    return dqmc_synchronize(h);
+}
+
+int dqmc_get_greens_eff(dqmc_handle *h, int32_t w, double *out)
+{
+    ENTER(h); WALKER_OK(h, w);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(out, h->greens + (size_t)w * h->nb * h->nn, sizeof(double) * h->nb * h->nn, hipMemcpyDeviceToHost));
+    return DQMC_OK;
+}
+int dqmc_set_greens_eff(dqmc_handle *h, int32_t w, const double *in)
+{
+    ENTER(h); WALKER_OK(h, w);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(h->greens + (size_t)w * h->nb * h->nn, in, sizeof(double) * h->nb * h->nn, hipMemcpyHostToDevice));
+    return DQMC_OK;
+}
+// greens!(mc): temp = greens*eT; out = eTinv*temp (DQMC.jl:721-730); result in tmp2
+static int true_greens(dqmc_handle *h, const double *src)
+{
+    CHK(run_gemm(h, gemm_base(h, U_(h, src), 0, C_(h, h->eT), 0, h->tmp1)));
+    CHK(run_gemm(h, gemm_base(h, C_(h, h->eTinv), 0, U_(h, h->tmp1), 0, h->tmp2)));
+    return 0;
+}
+int dqmc_get_greens(dqmc_handle *h, int32_t w, double *out)
+{
+    ENTER(h); WALKER_OK(h, w);
+    CHK(true_greens(h, h->greens));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(out, h->tmp2 + (size_t)w * h->nb * h->nn, sizeof(double) * h->nb * h->nn, hipMemcpyDeviceToHost));
+    return DQMC_OK;
+}
+
+// calculate_greens(mc, slice) (stack.jl:422-480)
+int dqmc_calculate_greens_at(dqmc_handle *h, int32_t w, int32_t slice, double *out)
+{
+    ENTER(h); WALKER_OK(h, w);
+    if (slice < 0 || slice > h->M) return fail(h, DQMC_ERR_INVALID, "slice out of range 0..slices");
+    const int n = h->n, M = h->M, s = h->s;
+    // right factor: Ur,Dr,Tr = B(slice+1)' ... B(M)'
+    CHK(set_identity(h, h->bufA)); CHK(set_identity(h, h->Ur)); CHK(set_ones(h, h->Dr)); CHK(set_identity(h, h->Tr));
+    double *cur = h->bufA, *oth = h->bufB;
+    auto chain_step = [&](int k, bool dagger, bool stab, double *D, double *T, double *Ufinal) -> int {
+        GemmArgs g = dagger ? gemm_base(h, C_(h, h->eT2), 1, U_(h, cur), 0, oth)
+                            : gemm_base(h, C_(h, h->eT2), 0, U_(h, cur), 0, oth);
+        if (dagger) { g.rowscale = vs_conf(h, k, +1); g.row_first = 1; }
+        else g.kscale = vs_conf(h, k, +1);
+        if (stab) g.colscale = vs_arr(D, n);
+        CHK(run_gemm(h, g));
+        std::swap(cur, oth);
+        if (stab) {
+            // udt(curr_U, D, tmp1); T = tmp1 * T  (stack.jl:441-444)
+            CHK(udt(h, cur, Ufinal ? Ufinal : oth, D, h->tmp2, 1));
+            if (!Ufinal) std::swap(cur, oth);
+            CHK(copy_mat(h, h->tmp1, T));
+            CHK(run_gemm(h, gemm_base(h, U_(h, h->tmp2), 0, U_(h, h->tmp1), 0, T)));
+        }
+        return 0;
+    };
+    if (slice + 1 <= M) {
+        for (int k = M; k >= slice + 1; --k) CHK(chain_step(k, true, k % s == 0, h->Dr, h->Tr, nullptr));
+        // final: tmp1 = curr_U*Diagonal(Dr); udt(Ur, Dr, tmp1); Tr = tmp1*Tr
+        GemmArgs g = gemm_base(h, U_(h, cur), 0, U_(h, h->qrS), 0, oth);
+        CHK(set_identity(h, h->qrS));
+        g.colscale = vs_arr(h->Dr, n);
+        CHK(run_gemm(h, g));
+        std::swap(cur, oth);
+        CHK(udt(h, cur, h->Ur, h->Dr, h->tmp2, 1));
+        CHK(copy_mat(h, h->tmp1, h->Tr));
+        CHK(run_gemm(h, gemm_base(h, U_(h, h->tmp2), 0, U_(h, h->tmp1), 0, h->Tr)));
+    }
+    // left factor: Ul,Dl,Tl = B(slice) ... B(1)
+    CHK(set_identity(h, h->bufA)); CHK(set_identity(h, h->Ul)); CHK(set_ones(h, h->Dl)); CHK(set_identity(h, h->Tl));
+    cur = h->bufA; oth = h->bufB;
+    if (slice >= 1) {
+        for (int k = 1; k <= slice; ++k) CHK(chain_step(k, false, k % s == 0, h->Dl, h->Tl, nullptr));
+        GemmArgs g = gemm_base(h, U_(h, cur), 0, U_(h, h->qrS), 0, oth);
+        CHK(set_identity(h, h->qrS));
+        g.colscale = vs_arr(h->Dl, n);
+        CHK(run_gemm(h, g));
+        std::swap(cur, oth);
+        CHK(udt(h, cur, h->Ul, h->Dl, h->tmp2, 1));
+        CHK(copy_mat(h, h->tmp1, h->Tl));
+        CHK(run_gemm(h, gemm_base(h, U_(h, h->tmp2), 0, U_(h, h->tmp1), 0, h->Tl)));
+    }
+    CHK(calculate_greens(h, h->greens_temp));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(out, h->greens_temp + (size_t)w * h->nb * h->nn, sizeof(double) * h->nb * h->nn,
+                     hipMemcpyDeviceToHost));
+    return DQMC_OK;
+}
+
+int dqmc_wrap_greens(dqmc_handle *h, int32_t slice, int32_t direction)
+{
+    ENTER(h);
+    if (direction != 1 && direction != -1) return fail(h, DQMC_ERR_INVALID, "direction must be +1 or -1");
+    const int l = direction == 1 ? slice : slice - 1;
+    if (l < 1 || l > h->M) return fail(h, DQMC_ERR_INVALID, "wrap_greens: slice out of range");
+    CHK(wrap_greens(h, h->greens, slice, direction));
+    return dqmc_synchronize(h);
+}
+
+static void conv_mag(const DevMagStats &d, dqmc_magstats &o) { o.max = d.max; o.min = d.min; o.sum = d.sum; o.count = d.count; }
+int dqmc_get_stats(dqmc_handle *h, int32_t w, dqmc_stats *out)
+{
+    ENTER(h); WALKER_OK(h, w);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    DevStats d;
+    HIPCHK(hipMemcpy(&d, h->stats + w, sizeof(d), hipMemcpyDeviceToHost));
+    out->prop_local = d.prop_local;
+    out->acc_local = d.acc_local;
+    out->imaginary_probability = {-INFINITY, INFINITY, 0.0, 0};
+    conv_mag(d.negative_probability, out->negative_probability);
+    conv_mag(d.propagation_error, out->propagation_error);
+    return DQMC_OK;
+}
+
+int dqmc_accumulate_greens(dqmc_handle *h)
+{
+    ENTER(h); NEED_PREPARED(h);
+    CHK(true_greens(h, h->greens));
+    {
+        Timed t(h, DQMC_K_MISC);
+        HIPCHK(launch_accumulate(h->n, h->nb, h->W, h->tmp2, h->nn, h->acc, h->stream));
+    }
+    return DQMC_OK;
+}
+int dqmc_accumulator_size(dqmc_handle *h, size_t *n)
+{
+    if (!h || !n) return DQMC_ERR_INVALID;
+    *n = h->acc_n;
+    return DQMC_OK;
+}
+int dqmc_reset_accumulators(dqmc_handle *h)
+{
+    ENTER(h);
+    HIPCHK(hipMemsetAsync(h->acc, 0, h->acc_n * sizeof(double), h->stream));
+    return DQMC_OK;
+}
+int dqmc_get_accumulators(dqmc_handle *h, double *host_out)
+{
+    ENTER(h);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(host_out, h->acc, h->acc_n * sizeof(double), hipMemcpyDeviceToHost));
+    return DQMC_OK;
+}
+int dqmc_export_accumulators(dqmc_handle *h, void *device_out)
+{
+    ENTER(h);
+    HIPCHK(hipMemcpyAsync(device_out, h->acc, h->acc_n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return DQMC_OK;
+}
+
+int dqmc_timing_enable(dqmc_handle *h, int32_t on)
+{
+    ENTER(h);
+    CHK(timing_drain(h));
+    h->timing = on != 0;
+    for (int i = 0; i < DQMC_K_COUNT; ++i) { h->fam_ms[i] = 0; h->fam_n[i] = 0; }
+    return DQMC_OK;
+}
+int dqmc_timing_get(dqmc_handle *h, double *ms, int64_t *launches)
+{
+    ENTER(h);
+    CHK(timing_drain(h));
+    for (int i = 0; i < DQMC_K_COUNT; ++i) {
+        if (ms) ms[i] = h->fam_ms[i];
+        if (launches) launches[i] = h->fam_n[i];
+    }
+    return DQMC_OK;
+}
+
+// ---------------------------------------------------------------------------
+// stand-alone batched primitives (host in / host out)
+// ---------------------------------------------------------------------------
+namespace {
+struct Scratch {  // a throw-away handle-like context for the primitive entry points
+    dqmc_handle h;
+    int ok = 0;
+};
+static int scratch_init(dqmc_handle *h, int device_id, int n, int batch)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(nullptr, DQMC_ERR_NO_DEVICE, "no HIP device visible");
+    if (device_id < 0 || device_id >= ndev) return fail(nullptr, DQMC_ERR_INVALID, "device_id out of range");
+    if (n < 1 || n > 1024 || batch < 1) return fail(nullptr, DQMC_ERR_INVALID, "n must be 1..1024 and batch >= 1");
+    h->p.device_id = device_id;
+    h->n = h->N = n;
+    h->nb = 1;
+    h->W = h->units = batch;
+    h->nn = (long)n * n;
+    HIPCHK(hipSetDevice(device_id));
+    HIPCHK(hipStreamCreate(&h->stream));
+    return 0;
+}
+static void scratch_free(dqmc_handle *h)
+{
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (void *q : h->allocs) (void)hipFree(q);
+    h->allocs.clear();
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    h->stream = nullptr;
+}
+}  // namespace
+
+#define SCHK(expr)                                   \
+    do {                                             \
+        int rc_ = (expr);                            \
+        if (rc_ != 0) {                              \
+            g_create_error = h->err.empty() ? g_create_error : h->err; \
+            scratch_free(h);                         \
+            return rc_;                              \
+        }                                            \
+    } while (0)
+#define SHIP(expr)                                                       \
+    do {                                                                 \
+        hipError_t e_ = (expr);                                          \
+        if (e_ != hipSuccess) {                                          \
+            g_create_error = std::string(#expr) + ": " + hipGetErrorString(e_); \
+            scratch_free(h);                                             \
+            return DQMC_ERR_HIP;                                         \
+        }                                                                \
+    } while (0)
+
+int dqmc_vmul(int32_t device_id, int32_t n, int32_t batch, int32_t ta, int32_t tb, const double *A, const double *B,
+              double *C)
+{
+    dqmc_handle hh; dqmc_handle *h = &hh;
+    SCHK(scratch_init(h, device_id, n, batch));
+    const size_t un = (size_t)batch * h->nn;
+    double *dA, *dB, *dC;
+    SCHK(dalloc(h, &dA, un, false)); SCHK(dalloc(h, &dB, un, false)); SCHK(dalloc(h, &dC, un));
+    SHIP(hipMemcpy(dA, A, un * sizeof(double), hipMemcpyHostToDevice));
+    SHIP(hipMemcpy(dB, B, un * sizeof(double), hipMemcpyHostToDevice));
+    SCHK(run_gemm(h, gemm_base(h, U_(h, dA), ta != 0, U_(h, dB), tb != 0, dC)));
+    SHIP(hipStreamSynchronize(h->stream));
+    SHIP(hipMemcpy(C, dC, un * sizeof(double), hipMemcpyDeviceToHost));
+    scratch_free(h);
+    return DQMC_OK;
+}
+
+static int scratch_udt_bufs(dqmc_handle *h)
+{
+    const size_t un = (size_t)h->units * h->nn, uv = (size_t)h->units * h->n;
+    CHK(dalloc(h, &h->qrV, un)); CHK(dalloc(h, &h->qrW, un)); CHK(dalloc(h, &h->qrS, un));
+    CHK(dalloc(h, &h->tau, uv)); CHK(dalloc(h, &h->pivot, uv));
+    return 0;
+}
+
+int dqmc_udt_pivot(int32_t device_id, int32_t n, int32_t batch, double *U, double *D, double *T, int64_t *pivot,
+                   int32_t apply)
+{
+    dqmc_handle hh; dqmc_handle *h = &hh;
+    SCHK(scratch_init(h, device_id, n, batch));
+    const size_t un = (size_t)batch * h->nn, uv = (size_t)batch * n;
+    double *dU, *dD, *dT, *dTo;
+    SCHK(dalloc(h, &dU, un)); SCHK(dalloc(h, &dD, uv)); SCHK(dalloc(h, &dT, un, false)); SCHK(dalloc(h, &dTo, un));
+    SCHK(scratch_udt_bufs(h));
+    SHIP(hipMemcpy(dT, T, un * sizeof(double), hipMemcpyHostToDevice));
+    SCHK(udt(h, dT, dU, dD, dTo, apply != 0));
+    SHIP(hipStreamSynchronize(h->stream));
+    SHIP(hipMemcpy(U, dU, un * sizeof(double), hipMemcpyDeviceToHost));
+    SHIP(hipMemcpy(D, dD, uv * sizeof(double), hipMemcpyDeviceToHost));
+    SHIP(hipMemcpy(T, apply ? dTo : dT, un * sizeof(double), hipMemcpyDeviceToHost));
+    std::vector<int> piv(uv);
+    SHIP(hipMemcpy(piv.data(), h->pivot, uv * sizeof(int), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < uv; ++i) pivot[i] = (int64_t)piv[i] + 1;
+    scratch_free(h);
+    return DQMC_OK;
+}
+
+int dqmc_rdivp(int32_t device_id, int32_t n, int32_t batch, double *A, const double *T, const int64_t *pivot)
+{
+    dqmc_handle hh; dqmc_handle *h = &hh;
+    SCHK(scratch_init(h, device_id, n, batch));
+    const size_t un = (size_t)batch * h->nn, uv = (size_t)batch * n;
+    double *dA, *dT;
+    SCHK(dalloc(h, &dA, un, false)); SCHK(dalloc(h, &dT, un, false)); SCHK(dalloc(h, &h->pivot, uv));
+    std::vector<int> piv(uv);
+    for (size_t i = 0; i < uv; ++i) {
+        if (pivot[i] < 1 || pivot[i] > n) { scratch_free(h); return fail(nullptr, DQMC_ERR_INVALID, "pivot entry out of range"); }
+        piv[i] = (int)(pivot[i] - 1);
+    }
+    SHIP(hipMemcpy(dA, A, un * sizeof(double), hipMemcpyHostToDevice));
+    SHIP(hipMemcpy(dT, T, un * sizeof(double), hipMemcpyHostToDevice));
+    SHIP(hipMemcpy(h->pivot, piv.data(), uv * sizeof(int), hipMemcpyHostToDevice));
+    SCHK(rdivp(h, dA, dT));
+    SHIP(hipStreamSynchronize(h->stream));
+    SHIP(hipMemcpy(A, dA, un * sizeof(double), hipMemcpyDeviceToHost));
+    scratch_free(h);
+    return DQMC_OK;
+}
+
+int dqmc_calculate_greens(int32_t device_id, int32_t n, int32_t batch, const double *Ul, const double *Dl,
+                          const double *Tl, const double *Ur, const double *Dr, const double *Tr, double *G)
+{
+    dqmc_handle hh; dqmc_handle *h = &hh;
+    SCHK(scratch_init(h, device_id, n, batch));
+    const size_t un = (size_t)batch * h->nn, uv = (size_t)batch * n;
+    double *dG;
+    SCHK(dalloc(h, &h->Ul, un, false)); SCHK(dalloc(h, &h->Ur, un, false)); SCHK(dalloc(h, &h->Tl, un, false));
+    SCHK(dalloc(h, &h->Tr, un, false)); SCHK(dalloc(h, &h->Dl, uv, false)); SCHK(dalloc(h, &h->Dr, uv, false));
+    SCHK(dalloc(h, &dG, un));
+    SCHK(scratch_udt_bufs(h));
+    SHIP(hipMemcpy(h->Ul, Ul, un * sizeof(double), hipMemcpyHostToDevice));
+    SHIP(hipMemcpy(h->Ur, Ur, un * sizeof(double), hipMemcpyHostToDevice));
+    SHIP(hipMemcpy(h->Tl, Tl, un * sizeof(double), hipMemcpyHostToDevice));
+    SHIP(hipMemcpy(h->Tr, Tr, un * sizeof(double), hipMemcpyHostToDevice));
+    SHIP(hipMemcpy(h->Dl, Dl, uv * sizeof(double), hipMemcpyHostToDevice));
+    SHIP(hipMemcpy(h->Dr, Dr, uv * sizeof(double), hipMemcpyHostToDevice));
+    SCHK(calculate_greens(h, dG));
+    SHIP(hipStreamSynchronize(h->stream));
+    SHIP(hipMemcpy(G, dG, un * sizeof(double), hipMemcpyDeviceToHost));
+    scratch_free(h);
+    return DQMC_OK;
+}
+
+int dqmc_mfma_f64_peak(int32_t device_id, int32_t iters, double *tflops)
+{
+    dqmc_handle hh; dqmc_handle *h = &hh;
+    SCHK(scratch_init(h, device_id, 16, 1));
+    double *sink;
+    SCHK(dalloc(h, &sink, 16));
+    hipDeviceProp_t prop;
+    SHIP(hipGetDeviceProperties(&prop, device_id));
+    const int blocks = prop.multiProcessorCount * 2;  // 8 waves per CU = 2 per SIMD
+    hipEvent_t a, b;
+    SHIP(hipEventCreate(&a)); SHIP(hipEventCreate(&b));
+    SHIP(launch_mfma_peak(iters / 8 + 1, blocks, sink, h->stream));  // warm up
+    SHIP(hipEventRecord(a, h->stream));
+    SHIP(launch_mfma_peak(iters, blocks, sink, h->stream));
+    SHIP(hipEventRecord(b, h->stream));
+    SHIP(hipStreamSynchronize(h->stream));
+    float ms = 0.f;
+    SHIP(hipEventElapsedTime(&ms, a, b));
+    const double flops = (double)blocks * 4.0 /*waves*/ * (double)iters * 4.0 /*mfma*/ * 2.0 * 16 * 16 * 4;
+    *tflops = flops / (ms * 1e-3) / 1e12;
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    scratch_free(h);
+    return DQMC_OK;
+}
+
+}  // extern "C"

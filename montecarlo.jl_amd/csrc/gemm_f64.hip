@@ -1,0 +1,219 @@
+// gemm_f64.hip — batched fp64 GEMM on v_mfma_f64_16x16x4_f64 with the DQMC diagonal
+// scalings fused into operand load / epilogue.
+//
+// Stands in for the vmul! family of src/linalg/general.jl:7-56 and for every
+// multiply_*slice_matrix* of src/flavors/DQMC/slice_matrices.jl:42-76: the slice
+// matrix B_l = eT2*Diagonal(eV_l) is never materialised (slice_matrices.jl:23-39
+// does); eV_l is rebuilt from the Int8 HS field while the tile is staged.
+//
+// Tiling: one 64x64 C tile per 256-thread workgroup (4 waves as 2x2, each wave
+// 2x2 MFMA tiles of 16x16), BK = 16, LDS double buffered with register-staged
+// prefetch.  The MFMA is issued "transposed" (A-operand <- opB, B-operand <- opA)
+// so that the accumulator's lane index runs along m, the contiguous direction of
+// column-major C: stores are 128-byte segments.
+#include "kernels.h"
+
+namespace dqmc {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 64, BN = 64, BK = 16;
+// LDS row stride (doubles).  2*LS = 32 (mod 64) dwords puts the k and k+1 rows that
+// one 32-lane half reads with ds_read_b64 on disjoint bank halves.
+constexpr int LS = 80;
+
+__device__ __forceinline__ double vs_get(const VecSrc &v, int unit, int nb, int i)
+{
+    if (v.mode == 1) return v.d[(long)unit * v.stride + i];
+    if (v.mode == 3) return 1.0 / v.d[(long)unit * v.stride + i];
+    if (v.mode == 2) {
+        const int w = unit / nb, b = unit - w * nb;
+        const int8_t c = v.conf[(long)w * v.conf_stride + i];
+        return c > 0 ? v.cpos[b] : v.cneg[b];
+    }
+    return 1.0;
+}
+
+// "direct" tile: the 64-long index (m or n) is contiguous in memory.
+//   element(c, k) = p[c + ld*k]; thread -> k = tid/16, c = (tid%16)*4 .. +3
+// "transposing" tile: k is contiguous in memory.
+//   element(c, k) = p[k + ld*c]; thread -> c = tid/4, k = (tid%4)*4 .. +3
+template <bool KCONTIG>
+__device__ __forceinline__ void tile_load(const double *__restrict__ p, int ld, int c0, int cdim,
+                                          int k0, int kdim, int tid, double r[4])
+{
+    if (!KCONTIG) {
+        const int kk = k0 + (tid >> 4), cc = c0 + ((tid & 15) << 2);
+        const double *q = p + (long)ld * kk + cc;
+        if (kk < kdim && cc + 3 < cdim) {
+            r[0] = q[0]; r[1] = q[1]; r[2] = q[2]; r[3] = q[3];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) r[i] = (kk < kdim && cc + i < cdim) ? q[i] : 0.0;
+        }
+    } else {
+        const int cc = c0 + (tid >> 2), kk = k0 + ((tid & 3) << 2);
+        const double *q = p + (long)ld * cc + kk;
+        if (cc < cdim && kk + 3 < kdim) {
+            r[0] = q[0]; r[1] = q[1]; r[2] = q[2]; r[3] = q[3];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) r[i] = (cc < cdim && kk + i < kdim) ? q[i] : 0.0;
+        }
+    }
+}
+
+template <bool KCONTIG>
+__device__ __forceinline__ void tile_store(double (*Xs)[LS], int tid, const double r[4])
+{
+    if (!KCONTIG) {
+        double *d = &Xs[tid >> 4][(tid & 15) << 2];
+        d[0] = r[0]; d[1] = r[1]; d[2] = r[2]; d[3] = r[3];
+    } else {
+        const int c = tid >> 2, k = (tid & 3) << 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Xs[k + i][c] = r[i];
+    }
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, int tiles_m, int tiles_n)
+{
+    __shared__ double As[2][BK][LS];
+    __shared__ double Bs[2][BK][LS];
+
+    // XCD-aware map: consecutive block ids round-robin over the 8 XCDs, so all
+    // tiles of one unit are given ids with equal (id % 8) and share that XCD's L2.
+    const int bid = blockIdx.x, xcd = bid & 7, seq = bid >> 3;
+    const int T = tiles_m * tiles_n;
+    const int unit = (seq / T) * 8 + xcd;
+    if (unit >= g.n_units) return;
+    const int tile = seq % T;
+    const int m0 = (tile % tiles_m) * BM, n0 = (tile / tiles_m) * BN;
+    const int blk = unit % g.nb;
+
+    const double *__restrict__ A = g.A.p + (long)unit * g.A.stride_unit + (long)blk * g.A.stride_blk;
+    const double *__restrict__ B = g.B.p + (long)unit * g.B.stride_unit + (long)blk * g.B.stride_blk;
+    double *__restrict__ C = g.C + (long)unit * g.strideC;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave & 1) * 32, wn = (wave >> 1) * 32;
+    const int li = lane & 15, lq = lane >> 4;
+
+    d4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+
+    const int nk = (g.K + BK - 1) / BK;
+    double ra[4], rb[4];
+
+    auto load = [&](int kt) {
+        const int k0 = kt * BK;
+        tile_load<TA>(A, g.A.ld, m0, g.M, k0, g.K, tid, ra);
+        tile_load<!TB>(B, g.B.ld, n0, g.N, k0, g.K, tid, rb);
+        if (g.kscale.mode != 0) {
+            if (!TA) {
+                const int kk = k0 + (tid >> 4);
+                const double s = kk < g.K ? vs_get(g.kscale, unit, g.nb, kk) : 0.0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ra[i] *= s;
+            } else {
+                const int kk = k0 + ((tid & 3) << 2);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    ra[i] *= (kk + i < g.K) ? vs_get(g.kscale, unit, g.nb, kk + i) : 0.0;
+            }
+        }
+    };
+    auto store = [&](int buf) {
+        tile_store<TA>(As[buf], tid, ra);
+        tile_store<!TB>(Bs[buf], tid, rb);
+    };
+
+    load(0);
+    store(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) load(kt + 1);
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 4) {
+            const int kq = kk + lq;
+            const double a0 = As[cur][kq][wm + li], a1 = As[cur][kq][wm + 16 + li];
+            const double b0 = Bs[cur][kq][wn + li], b1 = Bs[cur][kq][wn + 16 + li];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a0, acc[0][0], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a1, acc[1][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a0, acc[0][1], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a1, acc[1][1], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store(cur ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: lane holds C[m = .. + li][n = .. + lq + 4r]
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+        const int m = m0 + wm + ti * 16 + li;
+        if (m >= g.M) continue;
+        const double rs = g.rowscale.mode ? vs_get(g.rowscale, unit, g.nb, m) : 1.0;
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wn + tj * 16 + lq + 4 * r;
+                if (n >= g.N) continue;
+                double v = acc[ti][tj][r];
+                const double cs = g.colscale.mode ? vs_get(g.colscale, unit, g.nb, n) : 1.0;
+                if (g.row_first) { v *= rs; v *= cs; } else { v *= cs; v *= rs; }
+                v *= g.alpha;
+                if (m == n) {
+                    v += g.ident;
+                    if (g.adddiag.mode) v += vs_get(g.adddiag, unit, g.nb, m);
+                }
+                double *c = C + (long)g.ldc * n + m;
+                if (g.beta) v += *c;
+                *c = v;
+            }
+        }
+    }
+}
+
+hipError_t launch_gemm(const GemmArgs &g, hipStream_t s)
+{
+    const int tm = (g.M + BM - 1) / BM, tn = (g.N + BN - 1) / BN;
+    const int groups = (g.n_units + 7) / 8;
+    dim3 grid(groups * 8 * tm * tn), block(256);
+    if (g.transA) {
+        if (g.transB) hipLaunchKernelGGL((gemm_kernel<true, true>), grid, block, 0, s, g, tm, tn);
+        else hipLaunchKernelGGL((gemm_kernel<true, false>), grid, block, 0, s, g, tm, tn);
+    } else {
+        if (g.transB) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, block, 0, s, g, tm, tn);
+        else hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, 0, s, g, tm, tn);
+    }
+    return hipGetLastError();
+}
+
+// fp64 MFMA peak probe: independent accumulators, no memory traffic.
+__global__ __launch_bounds__(256) void mfma_peak_kernel(int iters, double *sink)
+{
+    d4 a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
+    double x = 1.0 + threadIdx.x * 1e-9, y = 1.0 - threadIdx.x * 1e-9;
+    for (int i = 0; i < iters; ++i) {
+        a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(y, x, a1, 0, 0, 0);
+        a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, a2, 0, 0, 0);
+        a3 = __builtin_amdgcn_mfma_f64_16x16x4f64(y, y, a3, 0, 0, 0);
+    }
+    d4 t = a0 + a1 + a2 + a3;
+    if (t[0] + t[1] + t[2] + t[3] == 123.456) sink[0] = t[0];
+}
+hipError_t launch_mfma_peak(int iters, int blocks, double *sink, hipStream_t s)
+{
+    hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, s, iters, sink);
+    return hipGetLastError();
+}
+
+}  // namespace dqmc

@@ -1,0 +1,111 @@
+// kernels.h — launch interfaces of the gfx950 DQMC kernels (internal to libdqmc_hip.so).
+//
+// Data model: a "unit" is one n x n problem = (walker, block); unit = walker*nb + block.
+// Every per-unit matrix is column-major with leading dimension ld and lives at
+// base + unit*stride_unit + (unit % nb)*stride_blk  (stride_unit = 0 for the hopping
+// exponentials, which are shared by all walkers and indexed by block only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dqmc {
+
+// A length-n vector per unit that is either stored (d) or derived on the fly from
+// the HS field: exp(±lambda*conf[i,l]) takes only two values
+// (HubbardModelAttractive.jl:100-110, HubbardModelRepulsive.jl:113-126).
+struct VecSrc {
+    int mode;  // 0 = none (1.0), 1 = d[i], 2 = conf-derived, 3 = 1.0/d[i]
+    const double *d;
+    long stride;          // per unit
+    const int8_t *conf;   // conf + walker*conf_stride + i  (already offset to the slice)
+    long conf_stride;     // per walker
+    double cpos[2], cneg[2];  // value for conf=+1 / conf=-1, per block
+};
+static inline VecSrc vs_none() { VecSrc v = {}; v.mode = 0; return v; }
+static inline VecSrc vs_arr(const double *d, long stride) { VecSrc v = {}; v.mode = 1; v.d = d; v.stride = stride; return v; }
+static inline VecSrc vs_inv(const double *d, long stride) { VecSrc v = {}; v.mode = 3; v.d = d; v.stride = stride; return v; }
+
+struct MatRef {
+    const double *p;
+    long stride_unit, stride_blk;
+    int ld;
+};
+static inline MatRef mat(const double *p, long su, int ld, long sb = 0) { MatRef m = {p, su, sb, ld}; return m; }
+
+// C[u] = beta*C[u] + epi( alpha * opA(A[u]) * diag(kscale) * opB(B[u]) ) + ident*I + diag(adddiag)
+// epi applies colscale (index n) and rowscale (index m); row_first selects the order.
+struct GemmArgs {
+    int M, N, K;
+    int n_units, nb;
+    MatRef A, B;
+    double *C; long strideC; int ldc;
+    int transA, transB;
+    VecSrc kscale, colscale, rowscale, adddiag;
+    int row_first;
+    double alpha;   // scale of the product
+    double ident;   // added on the diagonal
+    int beta;       // 0: overwrite, 1: accumulate into C
+};
+hipError_t launch_gemm(const GemmArgs &g, hipStream_t s);
+
+// Column-pivoted Householder QR, in place (udt_AVX_pivot! "QR decomposition" loop,
+// src/linalg/UDT.jl:212-246).  On exit A holds R on/above the diagonal and the
+// Householder vectors below it (unit diagonal implied), tau[n], pivot[n] (0-based:
+// column j of the factored matrix is original column pivot[j]).
+hipError_t launch_qr_pivot(int n, int n_units, double *A, long strideA, double *tau, int *pivot,
+                           hipStream_t s);
+
+// After launch_qr_pivot: D = |diag R| (UDT.jl:268-272); V = unit-lower Householder
+// vectors (n x n, explicit zeros/ones); T = D^-1 R:
+//   apply_pivot = 1: Tout[i, pivot[j]] = R[i,j]/D[i], zero elsewhere (UDT.jl:283-297), out of place
+//   apply_pivot = 0: A[i,j] *= 1/D[i] for j >= i in place, below-diagonal left dirty (UDT.jl:298-306)
+hipError_t launch_udt_finish(int n, int n_units, double *A, long strideA, const int *pivot, double *D,
+                             long strideD, double *V, long strideV, double *Tout, long strideT,
+                             int apply_pivot, hipStream_t s);
+
+// X = gather(A)[:, pivot] * triu(T)^-1 written to Out (rdivp!, src/linalg/general.jl:138-166).
+// pivot may be null (identity).  If dmul != null the diagonal of T is ignored and
+// column j is multiplied by dmul[j] instead of divided by T[j,j] (used with the
+// compact-WY triangle, whose inverse diagonal is tau).
+hipError_t launch_trsm_right_upper(int n, int n_units, const double *A, long strideA, const double *T,
+                                   long strideT, const int *pivot, const double *dmul, long strideV,
+                                   double *Out, long strideOut, hipStream_t s);
+
+// One chunk of sweep_spatial (DQMC.jl:546-582): sites [site0, site0+nsites) of the
+// current slice with delayed rank-1 updates; writes the accepted update vectors
+// (Uout: n x KD, VTout: n x KD, zero padded) for the flush GEMM G += Uout*VTout'.
+struct SweepConsts {
+    // per conf value index ci = (conf>0): attractive gamma (Attractive.jl:121) and
+    // exp(-dE_boson); repulsive Delta_up, Delta_dn (Repulsive.jl:139-141)
+    double gamma[2], ebos[2], dup[2], ddn[2];
+};
+struct WalkerRng {           // device-resident, one per walker
+    unsigned long long seed;
+    unsigned long long draw;       // draws consumed (philox counter or array cursor)
+    const double *uniforms;        // non-null: host-supplied stream
+    unsigned long long n_uniforms;
+    int exhausted;
+};
+struct DevMagStats { double max, min, sum; long long count; };
+struct DevStats {
+    long long prop_local, acc_local;
+    DevMagStats negative_probability, propagation_error;
+};
+int sweep_kd(int n, int nb);  // chunk length (update slots per flush) for this problem size
+hipError_t launch_sweep_chunk(int n, int nb, int n_walkers, int model, double *G, long strideG,
+                              int8_t *conf_slice, long conf_stride, int site0, int nsites,
+                              double *Uout, double *VTout, long strideUV, SweepConsts sc,
+                              WalkerRng *rng, DevStats *stats, int check_sign, hipStream_t s);
+
+// small helpers
+hipError_t launch_set_identity(int n, int count, double *A, long stride, hipStream_t s);
+hipError_t launch_fill(double *p, size_t n, double v, hipStream_t s);
+// per walker max|A-B| over its nb blocks; pushes log10 into stats.propagation_error if > 1e-7
+hipError_t launch_prop_check(int n, int nb, int n_walkers, const double *A, const double *B,
+                             long stride_unit, DevStats *stats, hipStream_t s);
+// acc += sum over walkers of G, G.^2, 1-diag(G); layout documented in include/dqmc_hip.h
+hipError_t launch_accumulate(int n, int nb, int n_walkers, const double *G, long stride_unit,
+                             double *acc, hipStream_t s);
+hipError_t launch_mfma_peak(int iters, int blocks, double *sink, hipStream_t s);
+
+}  // namespace dqmc

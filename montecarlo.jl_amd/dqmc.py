@@ -1,0 +1,362 @@
+"""DQMC flavor for a batch of walkers on one MI355X (mirror of src/flavors/DQMC/DQMC.jl).
+
+The object keeps the reference's names (`p`, `a`, `conf`, `propagate`, `sweep_spatial`,
+`update`, `run`, `greens`, `current_slice`, ...) so that parity tests read like the
+reference's tests; every numerical method is a call into libdqmc_hip.so.  One DQMC
+object = `n_walkers` independent Markov chains advancing in lockstep."""
+import ctypes as C
+import time
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, dptr, i64ptr, lib
+from .models import rand_conf
+
+
+@dataclass
+class DQMCParameters:
+    """DQMC.jl:52-125"""
+    thermalization: int = 100
+    sweeps: int = 100
+    check_sign_problem: bool = True
+    check_propagation_error: bool = True
+    safe_mult: int = 10
+    delta_tau: float = 0.1
+    beta: float = 1.0
+    slices: int = 10
+    measure_rate: int = 10
+
+    @staticmethod
+    def resolve(**kw):
+        """the (beta, delta_tau, slices) resolution rules of DQMC.jl:84-110"""
+        keys = set(k for k in ("beta", "delta_tau", "slices") if k in kw)
+        if keys == {"beta"}:
+            kw["delta_tau"] = 0.1
+            keys.add("delta_tau")
+        if keys == {"delta_tau", "beta", "slices"}:
+            slices = int(round(kw["beta"] / kw["delta_tau"]))
+            if slices != kw["slices"]:
+                raise ValueError("Given slices (%d) does not match calculated slices beta/delta_tau ≈ %d"
+                                 % (kw["slices"], slices))
+        elif keys == {"beta", "slices"}:
+            kw["delta_tau"] = kw["beta"] / kw["slices"]
+        elif keys == {"delta_tau", "slices"}:
+            kw["beta"] = kw["delta_tau"] * kw["slices"]
+        elif keys == {"delta_tau", "beta"}:
+            kw["slices"] = int(round(kw["beta"] / kw["delta_tau"]))
+        else:
+            raise ValueError("Invalid keyword arguments to DQMCParameters: %s" % sorted(keys))
+        return DQMCParameters(**kw)
+
+
+def hopping_exponentials(T, delta_tau):
+    """init_hopping_matrix_exp (stack.jl:167-181).  Julia's exp(::Matrix) uses the
+    Hermitian eigen-decomposition for a symmetric argument."""
+    w, V = np.linalg.eigh(-0.5 * delta_tau * T)
+    eT = (V * np.exp(w)) @ V.T
+    w, V = np.linalg.eigh(0.5 * delta_tau * T)
+    eTinv = (V * np.exp(w)) @ V.T
+    return eT, eTinv, eT @ eT, eTinv @ eTinv
+
+
+class DQMCAnalysis:
+    """DQMC.jl:36-47 for one walker"""
+
+    def __init__(self, st):
+        self.prop_local = st.prop_local
+        self.acc_local = st.acc_local
+        self.acc_rate = st.acc_local / st.prop_local if st.prop_local else 0.0
+        self.imaginary_probability = st.imaginary_probability
+        self.negative_probability = st.negative_probability
+        self.propagation_error = st.propagation_error
+
+
+class DQMC:
+    """DQMC(model; beta, delta_tau=0.1, safe_mult=10, ...) (DQMC.jl:250-289) for
+    `n_walkers` chains on device `device_id`.  `seed` keys the initial HS fields and the
+    Metropolis streams of walker w as `seed + first_walker + w`, so results do not depend
+    on how walkers are distributed over devices."""
+
+    def __init__(self, model, n_walkers=1, device_id=0, seed=123, first_walker=0, thermalization=100, sweeps=100,
+                 safe_mult=10, measure_rate=10, check_sign_problem=True, check_propagation_error=True, **kw):
+        self.model = model
+        self.p = DQMCParameters.resolve(thermalization=thermalization, sweeps=sweeps, safe_mult=safe_mult,
+                                        measure_rate=measure_rate, check_sign_problem=check_sign_problem,
+                                        check_propagation_error=check_propagation_error, **kw)
+        self.n_walkers = n_walkers
+        self.N = len(model.l)
+        self.nb = model.flv
+        self.last_sweep = 0
+        Ts = model.hopping_matrix()
+        exps = [hopping_exponentials(T, self.p.delta_tau) for T in Ts]
+        cat = lambda k: np.ascontiguousarray(np.concatenate([e[k].reshape(-1, order="F") for e in exps]))
+        self._eT, self._eTinv, self._eT2, self._eTinv2 = cat(0), cat(1), cat(2), cat(3)
+        self.hopping_matrix_exp = [e[0] for e in exps]
+        self.hopping_matrix_exp_inv = [e[1] for e in exps]
+        prm = _lib.Params(self.N, model.kind, self.p.slices, self.p.safe_mult, n_walkers, device_id,
+                          int(self.p.check_propagation_error), int(self.p.check_sign_problem), self.p.delta_tau,
+                          model.U, dptr(self._eT), dptr(self._eTinv), dptr(self._eT2), dptr(self._eTinv2))
+        self._h = C.c_void_p()
+        check(lib().dqmc_create(C.byref(prm), C.byref(self._h)))
+        # rand(DQMC, m, slices) per walker (DQMC.jl:273), then the Metropolis stream
+        self.seeds = [seed + first_walker + w for w in range(n_walkers)]
+        for w, s in enumerate(self.seeds):
+            rng = np.random.Generator(np.random.Philox(key=s))
+            self.set_conf(w, rand_conf(rng, self.N, self.p.slices))
+            self.seed(w, s)
+
+    # ---- lifetime
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib().dqmc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _c(self, rc):
+        check(rc, self._h)
+
+    # ---- state
+    def set_conf(self, walker, conf):
+        c = np.asfortranarray(np.asarray(conf, dtype=np.int8))
+        if c.shape != (self.N, self.p.slices):
+            raise ValueError("conf must have shape (n_sites, slices)")
+        self._c(lib().dqmc_set_conf(self._h, walker, c.ctypes.data))
+
+    def conf(self, walker=0):
+        c = np.zeros((self.N, self.p.slices), dtype=np.int8, order="F")
+        self._c(lib().dqmc_get_conf(self._h, walker, c.ctypes.data))
+        return c
+
+    def seed(self, walker, seed):
+        self._c(lib().dqmc_seed(self._h, walker, seed))
+
+    def set_uniforms(self, walker, u):
+        u = np.ascontiguousarray(u, dtype=np.float64)
+        self._c(lib().dqmc_set_uniforms(self._h, walker, dptr(u), u.size))
+
+    def uniforms_used(self, walker=0):
+        n = C.c_uint64()
+        self._c(lib().dqmc_uniforms_used(self._h, walker, C.byref(n)))
+        return n.value
+
+    def _state(self):
+        cs, d = C.c_int32(), C.c_int32()
+        self._c(lib().dqmc_get_state(self._h, C.byref(cs), C.byref(d)))
+        return cs.value, d.value
+
+    @property
+    def current_slice(self):
+        return self._state()[0]
+
+    @property
+    def direction(self):
+        return self._state()[1]
+
+    # ---- the sweep loop
+    def prepare(self):
+        """init!, build_stack, propagate (DQMC.jl:412-414)"""
+        self._c(lib().dqmc_prepare(self._h))
+
+    def build_stack(self):
+        self._c(lib().dqmc_build_stack(self._h))
+
+    def propagate(self):
+        self._c(lib().dqmc_propagate(self._h))
+
+    def sweep_spatial(self):
+        self._c(lib().dqmc_sweep_spatial(self._h))
+
+    def update(self):
+        self._c(lib().dqmc_update(self._h))
+
+    def sweep(self, n=1):
+        self._c(lib().dqmc_sweep(self._h, n))
+
+    def update_until_measure(self):
+        n = C.c_int32()
+        self._c(lib().dqmc_update_until_measure(self._h, C.byref(n)))
+        return n.value
+
+    def synchronize(self):
+        self._c(lib().dqmc_synchronize(self._h))
+
+    def run(self, verbose=False, on_measure=None):
+        """run!(mc) (DQMC.jl:369-515) without the host-side measurement framework: the
+        true Green's function is accumulated on the device every `measure_rate`-th sweep
+        after thermalization, at current_slice == 1 && direction == +1 (DQMC.jl:425-436)."""
+        self.prepare()
+        self.reset_accumulators()
+        total = self.p.thermalization + self.p.sweeps
+        t0 = time.time()
+        for i in range(self.last_sweep + 1, total + 1):
+            done = 0
+            while done < 2 * self.p.slices:
+                if self.current_slice == 1 and self.direction == 1 and done > 0:
+                    pass
+                # advance to the measurement point or to the end of the sweep
+                cs, d = self._state()
+                self._c(lib().dqmc_update(self._h))
+                done += 1
+                cs, d = self._state()
+                if cs == 1 and d == 1 and i > self.p.thermalization and i % self.p.measure_rate == 0:
+                    self._c(lib().dqmc_accumulate_greens(self._h))
+                    if on_measure is not None:
+                        on_measure(self, i)
+            self.last_sweep = i
+            if verbose and i % 10 == 0:
+                print("\t%d\n\t\tsweep dur: %.3fs" % (i, (time.time() - t0) / 10))
+                t0 = time.time()
+        self.synchronize()
+        return True
+
+    # ---- Green's functions
+    def _blocks(self, flat):
+        n = self.N
+        return [flat[b * n * n:(b + 1) * n * n].reshape((n, n), order="F") for b in range(self.nb)]
+
+    def greens_eff(self, walker=0):
+        """mc.s.greens"""
+        out = np.zeros(self.nb * self.N * self.N)
+        self._c(lib().dqmc_get_greens_eff(self._h, walker, dptr(out)))
+        return self._blocks(out)
+
+    def set_greens_eff(self, walker, blocks):
+        flat = np.ascontiguousarray(np.concatenate([np.asarray(b, dtype=np.float64).reshape(-1, order="F") for b in blocks]))
+        self._c(lib().dqmc_set_greens_eff(self._h, walker, dptr(flat)))
+
+    def greens(self, walker=0):
+        """greens(mc) (DQMC.jl:711-730)"""
+        out = np.zeros(self.nb * self.N * self.N)
+        self._c(lib().dqmc_get_greens(self._h, walker, dptr(out)))
+        return self._blocks(out)
+
+    def calculate_greens(self, slice_, walker=0):
+        """calculate_greens(mc, slice) (stack.jl:422-480)"""
+        out = np.zeros(self.nb * self.N * self.N)
+        self._c(lib().dqmc_calculate_greens_at(self._h, walker, slice_, dptr(out)))
+        return self._blocks(out)
+
+    def wrap_greens(self, slice_, direction):
+        self._c(lib().dqmc_wrap_greens(self._h, slice_, direction))
+
+    # ---- analysis / measurement sums
+    def analysis(self, walker=0):
+        st = _lib.Stats()
+        self._c(lib().dqmc_get_stats(self._h, walker, C.byref(st)))
+        return DQMCAnalysis(st)
+
+    def accumulate_greens(self):
+        self._c(lib().dqmc_accumulate_greens(self._h))
+
+    def reset_accumulators(self):
+        self._c(lib().dqmc_reset_accumulators(self._h))
+
+    def accumulator_size(self):
+        n = C.c_size_t()
+        self._c(lib().dqmc_accumulator_size(self._h, C.byref(n)))
+        return n.value
+
+    def accumulators(self):
+        out = np.zeros(self.accumulator_size())
+        self._c(lib().dqmc_get_accumulators(self._h, dptr(out)))
+        return out
+
+    def export_accumulators(self, device_ptr):
+        self._c(lib().dqmc_export_accumulators(self._h, C.c_void_p(device_ptr)))
+
+    def unpack_accumulators(self, acc):
+        """-> dict(G_mean, G2_mean, occupation_mean, count) per block"""
+        n, B = self.N, self.nb
+        cnt = acc[-1]
+        G = [acc[b * n * n:(b + 1) * n * n].reshape((n, n), order="F") / cnt for b in range(B)]
+        G2 = [acc[(B + b) * n * n:(B + b + 1) * n * n].reshape((n, n), order="F") / cnt for b in range(B)]
+        occ = [acc[2 * B * n * n + b * n:2 * B * n * n + (b + 1) * n] / cnt for b in range(B)]
+        return dict(G=G, G2=G2, occupation=occ, count=cnt)
+
+    # ---- instrumentation
+    def timing_enable(self, on=True):
+        self._c(lib().dqmc_timing_enable(self._h, int(on)))
+
+    def timing(self):
+        ms = np.zeros(len(_lib.K_FAMILIES))
+        n = np.zeros(len(_lib.K_FAMILIES), dtype=np.int64)
+        self._c(lib().dqmc_timing_get(self._h, dptr(ms), i64ptr(n)))
+        return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(_lib.K_FAMILIES)}
+
+
+# ---------------------------------------------------------------------------
+# batched linalg primitives (src/linalg), host arrays in/out
+def _batch(a):
+    a = np.asarray(a, dtype=np.float64)
+    if a.ndim == 2:
+        a = a[None]
+    return a
+
+
+def _pack(mats):
+    return np.ascontiguousarray(np.concatenate([m.reshape(-1, order="F") for m in mats]))
+
+
+def _unpack(flat, batch, n):
+    return np.stack([flat[i * n * n:(i + 1) * n * n].reshape((n, n), order="F") for i in range(batch)])
+
+
+def vmul(A, B, transa=False, transb=False, device_id=0):
+    """vmul!(C, A, B) and its adjoint/transpose variants (general.jl:7-56)"""
+    A, B = _batch(A), _batch(B)
+    batch, n = A.shape[0], A.shape[1]
+    a, b = _pack(A), _pack(B)
+    c = np.zeros_like(a)
+    check(lib().dqmc_vmul(device_id, n, batch, int(transa), int(transb), dptr(a), dptr(b), dptr(c)))
+    return _unpack(c, batch, n)
+
+
+def udt_AVX_pivot(X, apply_pivot=True, device_id=0):
+    """udt_AVX_pivot!(U, D, T, pivot, temp, Val(apply)) (UDT.jl:192-306) -> U, D, T, pivot(1-based)"""
+    X = _batch(X)
+    batch, n = X.shape[0], X.shape[1]
+    t = _pack(X)
+    u = np.zeros_like(t)
+    d = np.zeros(batch * n)
+    piv = np.zeros(batch * n, dtype=np.int64)
+    check(lib().dqmc_udt_pivot(device_id, n, batch, dptr(u), dptr(d), dptr(t), i64ptr(piv), int(apply_pivot)))
+    return _unpack(u, batch, n), d.reshape(batch, n), _unpack(t, batch, n), piv.reshape(batch, n)
+
+
+def rdivp(A, T, pivot, device_id=0):
+    """rdivp!(A, T, O, pivot) (general.jl:138-166)"""
+    A, T = _batch(A), _batch(T)
+    batch, n = A.shape[0], A.shape[1]
+    a, t = _pack(A), _pack(T)
+    piv = np.ascontiguousarray(np.asarray(pivot, dtype=np.int64).reshape(-1))
+    check(lib().dqmc_rdivp(device_id, n, batch, dptr(a), dptr(t), i64ptr(piv)))
+    return _unpack(a, batch, n)
+
+
+def calculate_greens_AVX(Ul, Dl, Tl, Ur, Dr, Tr, device_id=0):
+    """calculate_greens_AVX! (stack.jl:337-393)"""
+    Ul, Tl, Ur, Tr = _batch(Ul), _batch(Tl), _batch(Ur), _batch(Tr)
+    batch, n = Ul.shape[0], Ul.shape[1]
+    dl = np.ascontiguousarray(np.asarray(Dl, dtype=np.float64).reshape(-1))
+    dr = np.ascontiguousarray(np.asarray(Dr, dtype=np.float64).reshape(-1))
+    g = np.zeros(batch * n * n)
+    check(lib().dqmc_calculate_greens(device_id, n, batch, dptr(_pack(Ul)), dptr(dl), dptr(_pack(Tl)),
+                                      dptr(_pack(Ur)), dptr(dr), dptr(_pack(Tr)), dptr(g)))
+    return _unpack(g, batch, n)
+
+
+def mfma_f64_peak(iters=20000, device_id=0):
+    t = C.c_double()
+    check(lib().dqmc_mfma_f64_peak(device_id, iters, C.byref(t)))
+    return t.value
+
+
+def device_count():
+    return lib().dqmc_device_count()

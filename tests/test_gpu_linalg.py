@@ -1,0 +1,102 @@
+"""GPU parity of the batched linalg primitives against the CPU oracle and against the
+algebraic contracts of the reference's test/slice_matrices.jl:141-235."""
+import numpy as np
+import pytest
+
+from conftest import relerr
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-10  # north_star: Green's-function elements within 1e-10 relative
+
+
+@pytest.mark.parametrize("n,batch", [(16, 3), (64, 2), (100, 1), (256, 9)])
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_vmul_variants(gpu, n, batch, ta, tb):
+    rng = np.random.default_rng(n + 2 * ta + tb)
+    A = rng.standard_normal((batch, n, n))
+    B = rng.standard_normal((batch, n, n))
+    C = gpu.vmul(A, B, bool(ta), bool(tb))
+    for i in range(batch):
+        ref = (A[i].T if ta else A[i]) @ (B[i].T if tb else B[i])
+        assert relerr(C[i], ref) < 1e-13
+
+
+def test_vmul_layout_asymmetric(gpu):
+    """A = I against an asymmetric B catches a transposed accumulator map"""
+    n = 32
+    B = np.arange(n * n, dtype=np.float64).reshape(n, n)
+    C = gpu.vmul(np.eye(n), B)
+    assert np.array_equal(C[0], B)
+    C = gpu.vmul(B, np.eye(n))
+    assert np.array_equal(C[0], B)
+
+
+@pytest.mark.parametrize("n", [16, 64, 256])
+@pytest.mark.parametrize("apply_pivot", [True, False])
+def test_udt_contracts(gpu, O, n, apply_pivot):
+    """test/slice_matrices.jl:202-234: U*Diagonal(D)*T ≈ X, U unitary, D sorted positive;
+    Val(false): U*D*UpperTriangular(T)*P ≈ X with P[i, pivot[i]] = 1"""
+    rng = np.random.default_rng(n)
+    X = rng.standard_normal((4, n, n))
+    X[1] *= np.exp(rng.uniform(-20, 20, size=n))[None, :]   # graded columns as in a DQMC chain
+    U, D, T, piv = gpu.udt_AVX_pivot(X, apply_pivot)
+    for i in range(X.shape[0]):
+        assert relerr(U[i].T @ U[i], np.eye(n)) < 1e-12
+        assert np.all(D[i] > 0) and np.all(np.diff(D[i]) <= 1e-12 * D[i][:-1])
+        assert sorted(piv[i]) == list(range(1, n + 1))
+        if apply_pivot:
+            rec = (U[i] * D[i]) @ T[i]
+        else:
+            P = np.zeros((n, n)); P[np.arange(n), piv[i] - 1] = 1
+            rec = (U[i] * D[i]) @ np.triu(T[i]) @ P
+        scale = np.abs(X[i]).max(axis=0)
+        assert (np.abs(rec - X[i]) / scale[None, :]).max() < 1e-12
+        # same decomposition as the oracle when no pivot tie flips
+        Uo, Do, To, po = O.udt_pivot(X[i], apply_pivot)
+        if np.array_equal(po, piv[i]):
+            assert relerr(D[i], Do) < 1e-10
+            assert relerr(U[i], Uo) < 1e-9
+
+
+@pytest.mark.parametrize("n", [16, 64, 256])
+def test_rdivp(gpu, O, n):
+    """test/slice_matrices.jl:226-234: rdivp!(u, t, tmp, pivot) ≈ U*P'/UpperTriangular(T)"""
+    rng = np.random.default_rng(n + 1)
+    X = rng.standard_normal((n, n))
+    _, _, T, piv = O.udt_pivot(X, False)
+    A = rng.standard_normal((3, n, n))
+    out = gpu.rdivp(A, np.stack([T] * 3), np.stack([piv] * 3))
+    for i in range(3):
+        ref = O.rdivp(A[i], T, piv)
+        assert relerr(out[i], ref) < 1e-10
+
+
+@pytest.mark.parametrize("n", [16, 64, 256])
+def test_calculate_greens_AVX(gpu, O, n):
+    """G = [I + Ul Dl Tl (Ur Dr Tr)']^-1 (stack.jl:337-393) against the oracle and a direct inverse"""
+    rng = np.random.default_rng(n + 2)
+    batch = 2
+    args = []
+    for _ in range(batch):
+        Ul, _ = np.linalg.qr(rng.standard_normal((n, n)))
+        Ur, _ = np.linalg.qr(rng.standard_normal((n, n)))
+        Dl = np.sort(np.exp(rng.uniform(-3, 3, n)))[::-1]
+        Dr = np.sort(np.exp(rng.uniform(-3, 3, n)))[::-1]
+        Tl = np.eye(n) + 0.1 * rng.standard_normal((n, n))
+        Tr = np.eye(n) + 0.1 * rng.standard_normal((n, n))
+        args.append((Ul, Dl, Tl, Ur, Dr, Tr))
+    stack = lambda k: np.stack([a[k] for a in args])
+    G = gpu.calculate_greens_AVX(stack(0), stack(1), stack(2), stack(3), stack(4), stack(5))
+    for i, a in enumerate(args):
+        Go = O.calculate_greens(*a)
+        assert relerr(G[i], Go) < TOL
+        Ul, Dl, Tl, Ur, Dr, Tr = a
+        direct = np.linalg.inv(np.eye(n) + (Ul * Dl) @ Tl @ ((Ur * Dr) @ Tr).T)
+        assert relerr(G[i], direct) < 1e-8
+
+
+def test_mfma_peak_probe(gpu):
+    tf = gpu.mfma_f64_peak(20000)
+    print("fp64 MFMA probe: %.1f TFLOP/s" % tf)
+    assert tf > 10.0
