@@ -11,6 +11,7 @@
 // zero padded and the host flushes them with one MFMA GEMM (G0 += U' V) for all walkers.
 // This is a re-association of the reference's arithmetic only.
 #include "kernels.h"
+#include <cstdlib>
 
 namespace dqmc {
 
@@ -43,6 +44,15 @@ __device__ __forceinline__ void magstats_push(DevMagStats &s, double value)
     s.count += 1;
 }
 
+constexpr int SW_GROUP = 8;  // sites per unrolled group (static register indices inside)
+
+// Layout of the dynamic LDS region (doubles unless noted):
+//   Us[nb][KD][npad]   U'[t][m]  (thread t owns column t of every slot m)
+//   Vs[nb][KD][npad]   V[m][t]
+//   dg[2][KD]          current G[i,i] of the chunk's sites
+//   ul[KD]             the uniforms this chunk may consume, in draw order
+//   negv[KD]           negative determinant ratios met (sign-problem statistics)
+//   cs[KD] (int)       HS field of the chunk's sites
 template <int KD, int MAXT>
 __global__ __launch_bounds__(MAXT) void sweep_chunk_kernel(int n, int nb, int model, double *__restrict__ Gall,
                                                           long strideG, int8_t *__restrict__ conf_slice,
@@ -51,135 +61,139 @@ __global__ __launch_bounds__(MAXT) void sweep_chunk_kernel(int n, int nb, int mo
                                                           long strideUV, SweepConsts sc, WalkerRng *rngs,
                                                           DevStats *stats, int check_sign)
 {
-    __shared__ double dg[2][KD];          // current G[i,i] of the chunk's sites
-    __shared__ double Ui[2][KD][KD + 1];  // Ui[b][s][m] = U'[site0+s][m]
-    __shared__ double Vi[2][KD][KD + 1];  // Vi[b][m][s] = V[m][site0+s]
-    __shared__ int cs[KD];                // HS field of the chunk's sites
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int npad = (n + 63) & ~63;
+    double *Us = sm;
+    double *Vs = Us + (size_t)nb * KD * npad;
+    double *dg = Vs + (size_t)nb * KD * npad;  // [2][KD]
+    double *ul = dg + 2 * KD;
+    double *negv = ul + KD;
+    int *cs = (int *)(negv + KD);
 
     const int w = blockIdx.x;
-    const int npad = (n + 63) & ~63;
     const int tid = threadIdx.x;
     const int b = tid / npad, t = tid - b * npad;  // wave-uniform block index
     const bool active = t < n;
     const int unit = w * nb + b;
-    double *__restrict__ G = Gall + (long)unit * strideG;
+    const double *__restrict__ G = Gall + (long)unit * strideG;
     double *__restrict__ Uo = Uall + (long)unit * strideUV;
     double *__restrict__ VTo = VTall + (long)unit * strideUV;
     int8_t *__restrict__ cw = conf_slice + (long)w * conf_stride;
+    double *usb = Us + (size_t)b * KD * npad, *vsb = Vs + (size_t)b * KD * npad;
 
     const int sl = t - site0;  // my index inside the chunk, if any
     const bool in_chunk = active && sl >= 0 && sl < nsites;
-    if (in_chunk) dg[b][sl] = G[t + (long)n * t];
-    if (tid < nsites) cs[tid] = cw[site0 + tid];
-    WalkerRng rs = rngs[w];
-    unsigned long long draw = rs.draw;
-    int exhausted = 0;
-    long long n_acc = 0;
+    if (in_chunk) dg[b * KD + sl] = G[t + (long)n * t];
+    const WalkerRng rs = rngs[w];
+    if (tid < nsites) {
+        cs[tid] = cw[site0 + tid];
+        // the k-th uniform consumed by this chunk, whichever site consumes it (DQMC.jl:573)
+        const unsigned long long d = rs.draw + (unsigned long long)tid;
+        ul[tid] = rs.uniforms ? (d < rs.n_uniforms ? rs.uniforms[d] : 2.0) : philox_uniform(rs.seed, d);
+    }
+    int ndraw = 0, nneg = 0, exhausted = 0, cnt = 0;
+
+    // G0[:, site] and G0[site, :] for one group of sites, prefetched one group ahead
+    double colr[SW_GROUP], rowr[SW_GROUP], coln[SW_GROUP], rown[SW_GROUP];
+    auto fetch = [&](int s0, double (&cc)[SW_GROUP], double (&rr)[SW_GROUP]) {
+#pragma unroll
+        for (int q = 0; q < SW_GROUP; ++q) {
+            const bool ok = active && s0 + q < nsites;
+            cc[q] = ok ? G[t + (long)n * (site0 + s0 + q)] : 0.0;
+            rr[q] = ok ? G[(site0 + s0 + q) + (long)n * t] : 0.0;
+        }
+    };
+    fetch(0, colr, rowr);
     __syncthreads();
 
-    double Ureg[KD], Vreg[KD];
+    for (int s0 = 0; s0 < nsites; s0 += SW_GROUP) {
+        fetch(s0 + SW_GROUP, coln, rown);
 #pragma unroll
-    for (int m = 0; m < KD; ++m) { Ureg[m] = 0.0; Vreg[m] = 0.0; }
-    int cnt = 0;
-
-    double colc = 0.0, rowc = 0.0;
-    if (active) {
-        colc = G[t + (long)n * site0];
-        rowc = G[site0 + (long)n * t];
-    }
-    for (int s = 0; s < nsites; ++s) {
-        const int i = site0 + s;
-        double coln = 0.0, rown = 0.0;
-        if (active && s + 1 < nsites) {  // software prefetch of the next site's column / row of G0
-            coln = G[t + (long)n * (i + 1)];
-            rown = G[(i + 1) + (long)n * t];
-        }
-        const int c = cs[s];
-        const int ci = c > 0 ? 1 : 0;
-        const double d0 = dg[0][s];
-        double detratio, p, x0, x1 = 0.0;
-        if (model == 0) {  // HubbardModelAttractive.jl:113-127
-            const double gamma = sc.gamma[ci];
-            const double r = 1.0 + gamma * (1.0 - d0);
-            detratio = r * r;
-            p = sc.ebos[ci] * detratio;
-            x0 = gamma / r;  // Attractive.jl:149: x = gamma / (1 + gamma*IG[i])
-        } else {           // HubbardModelRepulsive.jl:128-156,174-191
-            const double d1 = dg[1][s];
-            const double D0 = sc.dup[ci], D1 = sc.ddn[ci];
-            const double R0 = 1.0 + D0 * (1.0 - d0), R1 = 1.0 + D1 * (1.0 - d1);
-            detratio = R0 * R1;
-            p = detratio;
-            const double inv_div = 1.0 / detratio;
-            x0 = (R1 * inv_div) * D0;
-            x1 = (R0 * inv_div) * D1;
-        }
-        if (check_sign && detratio < 0.0 && tid == 0) magstats_push(stats[w].negative_probability, detratio);
-
-        bool acc;
-        if (p > 1.0) acc = true;  // DQMC.jl:573: rand() is consumed only when p <= 1
-        else {
-            double u;
-            if (rs.uniforms) {
-                if (draw < rs.n_uniforms) u = rs.uniforms[draw];
-                else { u = 2.0; exhausted = 1; }
-            } else u = philox_uniform(rs.seed, draw);
-            ++draw;
-            acc = u < p;
-        }
-        if (acc) {
-            const int j = __builtin_amdgcn_readfirstlane(cnt);
-            const double xb = (b == 0) ? x0 : x1;
-            double cold = colc, rowd = rowc;
-#pragma unroll
-            for (int m = 0; m < KD; ++m) {
-                if (m < j) {
-                    cold += Ureg[m] * Vi[b][m][s];
-                    rowd += Ui[b][s][m] * Vreg[m];
+        for (int q = 0; q < SW_GROUP; ++q) {
+            const int s = s0 + q;
+            if (s < nsites) {
+                const int i = site0 + s;
+                const int c = cs[s];
+                const int ci = c > 0 ? 1 : 0;
+                const double d0 = dg[s];
+                double detratio, p, x0, x1 = 0.0;
+                if (model == 0) {  // HubbardModelAttractive.jl:113-127
+                    const double gamma = sc.gamma[ci];
+                    const double r = 1.0 + gamma * (1.0 - d0);
+                    detratio = r * r;
+                    p = sc.ebos[ci] * detratio;
+                    x0 = gamma / r;  // Attractive.jl:149: x = gamma / (1 + gamma*IG[i])
+                } else {           // HubbardModelRepulsive.jl:128-156,174-191
+                    const double d1 = dg[KD + s];
+                    const double D0 = sc.dup[ci], D1 = sc.ddn[ci];
+                    const double R0 = 1.0 + D0 * (1.0 - d0), R1 = 1.0 + D1 * (1.0 - d1);
+                    detratio = R0 * R1;
+                    p = detratio;
+                    const double inv_div = 1.0 / detratio;
+                    x0 = (R1 * inv_div) * D0;
+                    x1 = (R0 * inv_div) * D1;
+                }
+                if (check_sign && detratio < 0.0) {
+                    if (tid == 0) negv[nneg] = detratio;
+                    ++nneg;
+                }
+                bool acc;
+                if (p > 1.0) acc = true;  // DQMC.jl:573: rand() is consumed only when p <= 1
+                else {
+                    const double u = ul[ndraw++];
+                    if (u == 2.0) exhausted = 1;
+                    acc = u < p;
+                }
+                if (acc) {
+                    const int j = __builtin_amdgcn_readfirstlane(cnt);
+                    const double xb = (b == 0) ? x0 : x1;
+                    double cold = colr[q], rowd = rowr[q];
+#pragma unroll 4
+                    for (int m = 0; m < j; ++m) {
+                        cold += usb[m * npad + t] * vsb[m * npad + i];
+                        rowd += usb[m * npad + i] * vsb[m * npad + t];
+                    }
+                    const double ut = ((t == i) ? 1.0 : 0.0) - cold;  // IG = e_i - G[:,i]
+                    double newU = -(ut * xb), newV = rowd;
+                    if (!active) { newU = 0.0; newV = 0.0; }
+                    usb[j * npad + t] = newU;
+                    vsb[j * npad + t] = newV;
+                    if (in_chunk && sl > s) dg[b * KD + sl] += newU * newV;  // sites <= s are done
+                    if (tid == 0) cs[s] = -c;  // flipped field, written back after the site loop
+                    ++cnt;
+                    __syncthreads();
                 }
             }
-            const double ut = ((t == i) ? 1.0 : 0.0) - cold;  // IG = e_i - G[:,i]
-            double newU = -(ut * xb), newV = rowd;
-            if (!active) { newU = 0.0; newV = 0.0; }
+        }
 #pragma unroll
-            for (int m = 0; m < KD; ++m) {
-                if (m == j) { Ureg[m] = newU; Vreg[m] = newV; }
-            }
-            if (active) {
-                Uo[t + (long)n * j] = newU;
-                VTo[t + (long)n * j] = newV;
-            }
-            if (in_chunk && sl > s) {  // sites <= s are never proposed again in this chunk
-                Ui[b][sl][j] = newU;
-                Vi[b][j][sl] = newV;
-                dg[b][sl] += newU * newV;
-            }
-            if (tid == 0) cw[i] = (int8_t)-c;
-            ++cnt;
-            ++n_acc;
-            __syncthreads();
-        }
-        colc = coln;
-        rowc = rown;
+        for (int q = 0; q < SW_GROUP; ++q) { colr[q] = coln[q]; rowr[q] = rown[q]; }
     }
-    // zero the unused update slots so that the flush GEMM can always run with K = KD
-    for (int m = cnt; m < KD; ++m) {
-        if (active) {
-            Uo[t + (long)n * m] = 0.0;
-            VTo[t + (long)n * m] = 0.0;
+    // No global stores inside the site loop.  The update vectors leave LDS here, zero padded
+    // to KD slots so that the flush GEMM G0 += U' V always runs with K = KD.
+    if (active) {
+        for (int m = 0; m < KD; ++m) {
+            Uo[t + (long)n * m] = m < cnt ? usb[m * npad + t] : 0.0;
+            VTo[t + (long)n * m] = m < cnt ? vsb[m * npad + t] : 0.0;
         }
     }
+    if (tid < nsites) cw[site0 + tid] = (int8_t)cs[tid];
     if (tid == 0) {
-        rngs[w].draw = draw;
+        for (int k = 0; k < nneg; ++k) magstats_push(stats[w].negative_probability, negv[k]);
+        rngs[w].draw = rs.draw + (unsigned long long)ndraw;
         if (exhausted) rngs[w].exhausted = 1;
         stats[w].prop_local += nsites;
-        stats[w].acc_local += n_acc;
+        stats[w].acc_local += cnt;
     }
 }
 
-// chunk length: 2*KD doubles of update vectors live in registers per thread, so the
-// 1024-thread configuration (128 VGPR budget) uses the shorter chunk
-int sweep_kd(int n, int nb) { return nb * ((n + 63) & ~63) <= 512 ? 32 : 16; }
+// chunk length: the update vectors of a chunk (2*KD*n doubles per block) live in LDS
+int sweep_kd(int n, int nb)
+{
+    const int npad = (n + 63) & ~63;
+    int kd = 32;
+    while (kd > 4 && (size_t)nb * 2 * kd * npad * sizeof(double) > 132 * 1024) kd >>= 1;
+    return kd;
+}
 
 hipError_t launch_sweep_chunk(int n, int nb, int n_walkers, int model, double *G, long strideG, int8_t *conf_slice,
                               long conf_stride, int site0, int nsites, double *Uout, double *VTout, long strideUV,
@@ -187,14 +201,35 @@ hipError_t launch_sweep_chunk(int n, int nb, int n_walkers, int model, double *G
 {
     const int npad = (n + 63) & ~63;
     const int threads = nb * npad;
-    if (threads > 1024 || nsites > sweep_kd(n, nb)) return hipErrorInvalidValue;
+    const int kd = sweep_kd(n, nb);
+    if (threads > 1024 || nsites > kd) return hipErrorInvalidValue;
     dim3 grid(n_walkers), block(threads);
-#define SW_LAUNCH(KD, MT)                                                                                      \
-    hipLaunchKernelGGL((sweep_chunk_kernel<KD, MT>), grid, block, 0, s, n, nb, model, G, strideG, conf_slice,  \
-                       conf_stride, site0, nsites, Uout, VTout, strideUV, sc, rng, stats, check_sign)
-    if (threads <= 256) SW_LAUNCH(32, 256);
-    else if (threads <= 512) SW_LAUNCH(32, 512);
-    else SW_LAUNCH(16, 1024);
+    static const char *dbg = getenv("DQMC_DEBUG_SWEEP");
+    if (dbg) nsites = atoi(dbg) < nsites ? atoi(dbg) : nsites;
+    const size_t lds = ((size_t)nb * 2 * kd * npad + 5 * kd) * sizeof(double) + 64;
+#define SW_LAUNCH(KD, MT)                                                                                       \
+    do {                                                                                                        \
+        static bool attr_set = false;                                                                           \
+        if (!attr_set) {                                                                                        \
+            (void)hipFuncSetAttribute((const void *)sweep_chunk_kernel<KD, MT>,                                 \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                  \
+            attr_set = true;                                                                                    \
+        }                                                                                                       \
+        hipLaunchKernelGGL((sweep_chunk_kernel<KD, MT>), grid, block, lds, s, n, nb, model, G, strideG,         \
+                           conf_slice, conf_stride, site0, nsites, Uout, VTout, strideUV, sc, rng, stats,       \
+                           check_sign);                                                                         \
+    } while (0)
+#define SW_BY_THREADS(KD)                          \
+    do {                                           \
+        if (threads <= 256) SW_LAUNCH(KD, 256);    \
+        else if (threads <= 512) SW_LAUNCH(KD, 512); \
+        else SW_LAUNCH(KD, 1024);                  \
+    } while (0)
+    if (kd == 32) SW_BY_THREADS(32);
+    else if (kd == 16) SW_BY_THREADS(16);
+    else if (kd == 8) SW_BY_THREADS(8);
+    else SW_BY_THREADS(4);
+#undef SW_BY_THREADS
 #undef SW_LAUNCH
     return hipGetLastError();
 }
