@@ -96,7 +96,8 @@ def main():
     mc_amd = g.load_package()
     model = mc_amd.HubbardModelAttractive(L, 2)
     mc = mc_amd.DQMC(model, beta=BETA, delta_tau=DTAU, safe_mult=SAFE_MULT, n_walkers=args.walkers,
-                     device_id=local_rank, seed=BASE_SEED, first_walker=rank * args.walkers)
+                     device_id=local_rank, seed=BASE_SEED,
+                     first_walker=mc_amd.walker_range(rank, n_gpus, args.walkers)[0])
     n, M, K = mc.N, mc.p.slices, mc.p.slices // mc.p.safe_mult
     mc.prepare()
     acc_dev = torch.zeros(mc.accumulator_size(), dtype=torch.float64, device="cuda:%d" % local_rank)
@@ -115,8 +116,7 @@ def main():
         if (i + 1) % mc.p.measure_rate == 0:  # measurement sums + RCCL reduction (DQMC.jl:429-436)
             mc.accumulate_greens()
             mc.export_accumulators(acc_dev.data_ptr())
-            if dist is not None:
-                dist.all_reduce(acc_dev)
+            mc_amd.reduce_accumulators(acc_dev, dist)
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:

@@ -8,6 +8,7 @@ from ._lib import DQMCError, lib  # noqa: F401
 from .lattices import Chain, SquareLattice, build_checkerboard  # noqa: F401
 from .models import (HubbardModel, HubbardModelAttractive, HubbardModelRepulsive,  # noqa: F401
                      rand_conf)
+from .sharding import reduce_accumulators, walker_range, walker_seeds  # noqa: F401
 from .dqmc import (DQMC, DQMCParameters, calculate_greens_AVX, device_count,  # noqa: F401
                    hopping_exponentials, mfma_f64_peak, rdivp, udt_AVX_pivot, vmul)
 

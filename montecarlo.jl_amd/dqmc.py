@@ -196,14 +196,8 @@ class DQMC:
         total = self.p.thermalization + self.p.sweeps
         t0 = time.time()
         for i in range(self.last_sweep + 1, total + 1):
-            done = 0
-            while done < 2 * self.p.slices:
-                if self.current_slice == 1 and self.direction == 1 and done > 0:
-                    pass
-                # advance to the measurement point or to the end of the sweep
-                cs, d = self._state()
+            for _ in range(2 * self.p.slices):
                 self._c(lib().dqmc_update(self._h))
-                done += 1
                 cs, d = self._state()
                 if cs == 1 and d == 1 and i > self.p.thermalization and i % self.p.measure_rate == 0:
                     self._c(lib().dqmc_accumulate_greens(self._h))

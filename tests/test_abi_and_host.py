@@ -1,0 +1,106 @@
+"""C-ABI surface and host logic, no GPU: the library loads, exports every symbol that
+include/dqmc_hip.h declares, validates its arguments, and the product path neither
+links nor imports the CPU oracle."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "dqmc_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dqmc_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported(mc_amd):
+    from montecarlo_jl_amd import _lib
+    L = C.CDLL(_lib.LIB_PATH)
+    names = header_functions()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(L, n), "symbol %s declared in include/dqmc_hip.h is not exported" % n
+    assert sorted(_lib.SIGNATURES) == names, "ctypes binding and header disagree"
+
+
+def test_no_device_and_argument_errors(mc_amd):
+    from montecarlo_jl_amd import _lib
+    lib = _lib.lib()
+    n = 16
+    eye = np.eye(n).reshape(-1).copy()
+    def params(**kw):
+        d = dict(n_sites=n, model_kind=0, slices=10, safe_mult=10, n_walkers=1, device_id=0,
+                 check_propagation_error=1, check_sign_problem=1, delta_tau=0.1, U=1.0)
+        d.update(kw)
+        return _lib.Params(d["n_sites"], d["model_kind"], d["slices"], d["safe_mult"], d["n_walkers"], d["device_id"],
+                           d["check_propagation_error"], d["check_sign_problem"], d["delta_tau"], d["U"],
+                           _lib.dptr(eye), _lib.dptr(eye), _lib.dptr(eye), _lib.dptr(eye))
+    h = C.c_void_p()
+    # stack.jl:115: slices must be divisible by safe_mult
+    assert lib.dqmc_create(C.byref(params(slices=15)), C.byref(h)) == _lib.ERR_INVALID
+    assert b"safe_mult" in lib.dqmc_last_error(None)
+    assert lib.dqmc_create(C.byref(params(model_kind=7)), C.byref(h)) == _lib.ERR_INVALID
+    assert lib.dqmc_create(C.byref(params(U=-1.0)), C.byref(h)) == _lib.ERR_INVALID
+    if lib.dqmc_device_count() == 0:
+        # no CPU fallback: without a device creation fails loudly
+        assert lib.dqmc_create(C.byref(params()), C.byref(h)) == _lib.ERR_NO_DEVICE
+        with pytest.raises(_lib.DQMCError):
+            mc_amd.DQMC(mc_amd.HubbardModelAttractive(4, 2), beta=1.0)
+        with pytest.raises(_lib.DQMCError):
+            mc_amd.vmul(np.eye(4), np.eye(4))
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import importlib.util, os\n"
+        "import __graft_entry__ as g\n"
+        "spec = importlib.util.spec_from_file_location('x_lib', os.path.join(g.PKG_DIR, '_lib.py'))\n"
+        "m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)\n"
+        "m.LIB_PATH = %r\n"
+        "try:\n    m.lib()\nexcept ImportError as e:\n    print('LOUD', e)\n" % (ROOT, str(tmp_path / "nope.so")))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert "LOUD" in out.stdout and "no CPU fallback" in out.stdout
+
+
+def test_product_does_not_touch_the_oracle():
+    pkg = os.path.join(ROOT, "montecarlo.jl_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")) or f == "Makefile":
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "dqmc_oracle" not in txt and "import oracle" not in txt and "from oracle" not in txt, f
+    # the shared library does not link the oracle either
+    out = subprocess.run(["ldd", os.path.join(pkg, "libdqmc_hip.so")], capture_output=True, text=True).stdout
+    assert "oracle" not in out
+
+
+def test_host_hopping_exponentials(mc_amd, O):
+    """init_hopping_matrix_exp (stack.jl:167-181): eT*eTinv = I, eT2 = eT*eT; same as the oracle's host code"""
+    T = mc_amd.HubbardModelAttractive(4, 2, mu=0.3).hopping_matrix()[0]
+    eT, eTinv, eT2, eTinv2 = mc_amd.hopping_exponentials(T, 0.1)
+    assert np.abs(eT @ eTinv - np.eye(16)).max() < 1e-14
+    assert np.abs(eT2 - eT @ eT).max() == 0.0
+    import scipy.linalg as sla
+    assert np.abs(eT - sla.expm(-0.05 * T)).max() < 1e-14
+    o = O.hopping_exponentials(T, 0.1)
+    assert np.array_equal(o[0], eT) and np.array_equal(o[3], eTinv2)
+
+
+def test_rand_conf_layout(mc_amd):
+    rng = np.random.Generator(np.random.Philox(key=5))
+    c = mc_amd.rand_conf(rng, 16, 10)
+    assert c.shape == (16, 10) and c.dtype == np.int8 and set(np.unique(c)) == {-1, 1} and c.flags.f_contiguous
+
+
+def test_sharding(mc_amd):
+    first, ids = mc_amd.walker_range(3, 8, 32)
+    assert first == 96 and ids == list(range(96, 128))
+    seeds = [s for r in range(4) for s in mc_amd.walker_seeds(123, r, 4, 2)]
+    assert seeds == list(range(123, 131))
