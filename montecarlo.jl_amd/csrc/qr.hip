@@ -10,6 +10,7 @@
 // registers anyway), so every trailing element is read once and written once per
 // step.  Column norms and reflector dot products are wavefront shuffle reductions.
 #include "kernels.h"
+#include <cstdlib>
 
 namespace dqmc {
 
@@ -167,9 +168,322 @@ __global__ __launch_bounds__(QR_THREADS) void qr_pivot_kernel(int n, double *__r
     }
 }
 
+// ---------------------------------------------------------------------------
+// On-chip variant for 128 < n <= 256: one workgroup of 512 threads (8 waves) keeps the matrix
+// next to the ALUs for the whole factorisation, so a step costs FMAs and LDS broadcasts instead
+// of an L2 round trip per trailing element.
+//
+//   lane l : row group rg = l & 7, column group cg = l >> 3;   wave w = 0..7
+//   rows       r = rg + 8 k               k = 0..31   (32 rows per thread)
+//   positions  p = 64 s + 8 w + cg        s = 0..3    (4 columns per thread)
+// Storage class of a position follows its life time (position p is dead after step p) and is
+// uniform per slot:   slot 0  [0,64)    stays in place in global memory / L2 (dead after 64 steps)
+//                     slot 1  [64,128)  LDS, padded column stride 264
+//                     slot 2,3 [128,256) registers, 2 x 32 doubles per thread
+// Liveness of a slot is wave-uniform (8 w + 7 + 64 s > j), so finished columns cost nothing.
+// Dot products of a column are reduced over its 8 row-group lanes with DPP (quad_perm,
+// row_half_mirror); norm partials go to LDS and are summed in fixed order by the pivot search.
+// A column swap j <-> jm moves 2 x 256 doubles through LDS between the 8 owner lanes of each
+// column.  The pivot rule is the reference's (norms from the updated matrix, first maximum).
+constexpr int QT_THREADS = 512;
+constexpr int QT_LSTRIDE = 264;  // LDS column stride in doubles (bank-conflict-free for 4 column groups)
+constexpr int QT_VS = 34;        // stride of the per-row-group reflector slices (conflict-free 16-byte broadcasts)
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double x)
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// sum over the 8 lanes {8g .. 8g+7}; every lane receives the total
+__device__ __forceinline__ double sum8(double x)
+{
+    x += dpp_f64<0xB1>(x);   // quad_perm [1,0,3,2]
+    x += dpp_f64<0x4E>(x);   // quad_perm [2,3,0,1]
+    x += dpp_f64<0x141>(x);  // row_half_mirror
+    return x;
+}
+
+// The reflector is kept permuted in LDS, vq[k] = v[rg + 8k] for this thread's row group, so that a
+// thread fetches two of its rows per 16-byte broadcast read.
+// Register-resident column: dot, update, norm partial (static indices, rows >= 32 KB0 only).
+// Only the first 4 k of a region can contain finished rows (r <= j): they alone need the norm mask.
+template <int KB0>
+__device__ __forceinline__ void qt_reg_col(double (&x)[32], const double *vq, double *nrmp, int rg, int p, int j,
+                                           double tj)
+{
+    double d = 0.0;
+#pragma unroll
+    for (int k = 4 * KB0; k < 32; k += 2) {
+        const double2 v2 = *reinterpret_cast<const double2 *>(vq + k);
+        d += v2.x * x[k];
+        d += v2.y * x[k + 1];
+    }
+    const double wv = (p > j) ? sum8(d) * tj : 0.0;  // finished columns are left untouched
+    double nr = 0.0;
+#pragma unroll
+    for (int k = 4 * KB0; k < 32; k += 2) {
+        const double2 v2 = *reinterpret_cast<const double2 *>(vq + k);
+        const double y0 = x[k] - v2.x * wv, y1 = x[k + 1] - v2.y * wv;
+        x[k] = y0;
+        x[k + 1] = y1;
+        if (k < 4 * KB0 + 4) {
+            nr += (rg + 8 * k > j ? 1.0 : 0.0) * (y0 * y0);
+            nr += (rg + 8 * (k + 1) > j ? 1.0 : 0.0) * (y1 * y1);
+        } else {
+            nr += y0 * y0;
+            nr += y1 * y1;
+        }
+    }
+    nrmp[rg * 256 + p] = nr;
+}
+
+// KB0 = j / 32: first row block (4 k = 32 rows) that still has unfinished rows
+template <int KB0>
+__device__ __forceinline__ void qt_step(int n, int j, double *__restrict__ A, double *__restrict__ tau,
+                                        double *Lc, double *colP, double *colJ, double *vbuf, double *nrmp,
+                                        double *dummy, int *pv, double *cand_v, int *cand_i, double (&x2)[32],
+                                        double (&x3)[32])
+{
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, rg = lane & 7, cg = lane >> 3;
+    const int pb = 8 * w + cg;                          // position of slot s is 64 s + pb
+    double *g0 = A + (long)n * pb;                      // slot 0: in place in global memory
+    double *l1 = Lc + pb * QT_LSTRIDE;                  // slot 1: LDS
+
+    // ---- A. pivot search: first maximum of the trailing column norms (UDT.jl:151-168).
+    // Wave w scans positions 32 w .. 32 w + 31 (norm partials summed in fixed order), the eight
+    // wave candidates meet in LDS and every thread finishes the search redundantly.
+    {
+        double best = -1.0;
+        int bi = 0x7fffffff;
+        const int p = 32 * w + (lane & 31);
+        if (lane < 32 && p >= j && p < n) {
+            double val = 0.0;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) val += nrmp[g * 256 + p];
+            best = val;
+            bi = p;
+        }
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) {
+            const double ov = __shfl_xor(best, off, 64);
+            const int oi = __shfl_xor(bi, off, 64);
+            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        if (lane == 0) {
+            cand_v[w] = best;
+            cand_i[w] = bi;
+        }
+    }
+    __syncthreads();
+    int jm = 0x7fffffff;
+    double maxval = -1.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const double ov = cand_v[q];
+        const int oi = cand_i[q];
+        if (ov > maxval || (ov == maxval && oi < jm)) { maxval = ov; jm = oi; }
+    }
+    if (jm >= n) { jm = j; maxval = 0.0; }
+
+    // ---- B. the pivot column and the column it displaces go to LDS (8 owner lanes each)
+    const int wm = (jm & 63) >> 3;  // owner wave of the pivot position
+    // Wave-uniform control flow only: every lane of the owner wave stores, the 56 lanes of the
+    // other column groups into a dummy area (lane-divergent bulk copies of the register tile make
+    // the register allocator spill it).  Two passes: one wave may own both columns.
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int p = pass == 0 ? jm : j;
+        if (!(pass == 1 && jm == j) && w == ((p & 63) >> 3)) {
+            double *dst = (cg == (p & 7)) ? (pass == 0 ? colP : colJ) : dummy;
+            const int sp = p >> 6;
+            if (sp == 3) {
+#pragma unroll
+                for (int k = 0; k < 32; ++k) dst[rg + 8 * k] = x3[k];
+            } else if (sp == 2) {
+#pragma unroll
+                for (int k = 0; k < 32; ++k) dst[rg + 8 * k] = x2[k];
+            } else if (sp == 1) {
+                for (int k = 0; k < 32; ++k) dst[rg + 8 * k] = l1[rg + 8 * k];
+            } else {
+#pragma unroll 16
+                for (int k = 0; k < 32; ++k) {
+                    const int r = rg + 8 * k;
+                    dst[r] = r < n ? g0[r] : 0.0;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // reflector (UDT.jl:133-148); column j is final: R above the diagonal, v below
+    const double xi1 = colP[j];
+    double tj = 0.0, nu = 0.0, xi = 1.0;
+    if (maxval != 0.0) {
+        nu = copysign(sqrt(maxval), xi1);
+        xi = xi1 + nu;
+        tj = xi / nu;
+    }
+    if (tid < 256) {
+        const int r = tid;
+        double vr = 0.0;
+        if (r < n) {
+            const double cv = colP[r];
+            double outv = cv;
+            vr = (r == j) ? 1.0 : 0.0;
+            if (maxval != 0.0) {
+                if (r == j) outv = -nu;
+                else if (r > j) { outv = cv / xi; vr = outv; }
+            }
+            // position j is dead from now on: its storage (wherever it was) is never read again,
+            // so the finished column goes straight to the output matrix
+            A[r + (long)n * j] = outv;
+        }
+        vbuf[(r & 7) * QT_VS + (r >> 3)] = vr;  // permuted: slice of row group r & 7
+    }
+    if (tid == 0) {
+        tau[j] = tj;
+        const int t = pv[j];
+        pv[j] = pv[jm];
+        pv[jm] = t;
+    }
+    if (jm != j && w == wm) {  // the displaced column moves into the storage of position jm
+        const bool mine = cg == (jm & 7);
+        const int sp = jm >> 6;
+        if (sp == 3) {
+#pragma unroll
+            for (int k = 0; k < 32; ++k) { const double cc = colJ[rg + 8 * k]; x3[k] = mine ? cc : x3[k]; }
+        } else if (sp == 2) {
+#pragma unroll
+            for (int k = 0; k < 32; ++k) { const double cc = colJ[rg + 8 * k]; x2[k] = mine ? cc : x2[k]; }
+        } else if (mine) {
+            if (sp == 1) {
+                for (int k = 0; k < 32; ++k) l1[rg + 8 * k] = colJ[rg + 8 * k];
+            } else {
+                for (int k = 0; k < 32; ++k) {
+                    const int r = rg + 8 * k;
+                    if (r < n) g0[r] = colJ[r];
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- C. apply H_j to the trailing columns (reflectorApply!, UDT.jl:32-50); norms for step j+1.
+    // Finished rows inside a live row block have v = 0 (no effect on dot/update) and are masked in the norm.
+    const double *vq = vbuf + rg * QT_VS;
+    if (8 * w + 7 + 192 > j) qt_reg_col<KB0>(x3, vq, nrmp, rg, 192 + pb, j, tj);
+    if (KB0 < 6 && 8 * w + 7 + 128 > j) qt_reg_col<KB0>(x2, vq, nrmp, rg, 128 + pb, j, tj);
+    if (KB0 < 4 && 8 * w + 7 + 64 > j) {  // slot 1: LDS resident, rolled loops
+        double d = 0.0;
+#pragma unroll 8
+        for (int k = 4 * KB0; k < 32; ++k) d += vq[k] * l1[rg + 8 * k];
+        const double wv = (64 + pb > j) ? sum8(d) * tj : 0.0;
+        double nr = 0.0;
+#pragma unroll 8
+        for (int k = 4 * KB0; k < 32; ++k) {
+            const int r = rg + 8 * k;
+            const double y = l1[r] - vq[k] * wv;
+            l1[r] = y;
+            nr += (r > j ? 1.0 : 0.0) * (y * y);
+        }
+        nrmp[rg * 256 + 64 + pb] = nr;
+    }
+    if (KB0 < 2 && 8 * w + 7 > j) {       // slot 0: in place in global memory (L2), the column is read twice
+        double d = 0.0;
+#pragma unroll 16
+        for (int k = 4 * KB0; k < 32; ++k) {
+            const int r = rg + 8 * k;
+            d += vq[k] * (r < n ? g0[r] : 0.0);
+        }
+        const double wv = (pb > j) ? sum8(d) * tj : 0.0;
+        double nr = 0.0;
+#pragma unroll 16
+        for (int k = 4 * KB0; k < 32; ++k) {
+            const int r = rg + 8 * k;
+            if (r < n) {
+                const double y = g0[r] - vq[k] * wv;
+                g0[r] = y;
+                nr += (r > j ? 1.0 : 0.0) * (y * y);
+            }
+        }
+        nrmp[rg * 256 + pb] = nr;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(QT_THREADS) void qr_tile256_kernel(int n, int nsteps, double *__restrict__ Aall, long strideA,
+                                                               double *__restrict__ tauall,
+                                                               int *__restrict__ pivall)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    __shared__ double cand_v[8];
+    __shared__ int cand_i[8];
+    double *Lc = sm;                        // [64][QT_LSTRIDE] positions 64..127
+    double *colP = Lc + 64 * QT_LSTRIDE;    // [256] pivot column
+    double *colJ = colP + 256;              // [256] column that sat at position j
+    double *vbuf = colJ + 256;              // [8][QT_VS] reflector, permuted by row group
+    double *nrmp = vbuf + 8 * QT_VS;        // [8][256] norm partials per row group
+    double *dummy = nrmp + 8 * 256;         // [256] sink for the non-owner lanes of a column copy
+    int *pv = (int *)(dummy + 256);         // [256] pivot vector
+    const int unit = blockIdx.x;
+    double *__restrict__ A = Aall + (long)unit * strideA;
+    double *__restrict__ tau = tauall + (long)unit * n;
+    int *__restrict__ piv = pivall + (long)unit * n;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, rg = lane & 7, cg = lane >> 3;
+    const int pb = 8 * w + cg;
+
+    double x2[32], x3[32];
+    {   // load the on-chip part of the matrix and the initial norm partials
+        double n0 = 0.0, n1 = 0.0, n2 = 0.0, n3 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            const int r = rg + 8 * k;
+            const bool rok = r < n;
+            const double a0 = (rok && pb < n) ? A[r + (long)n * pb] : 0.0;
+            const double a1 = (rok && pb + 64 < n) ? A[r + (long)n * (pb + 64)] : 0.0;
+            const double a2 = (rok && pb + 128 < n) ? A[r + (long)n * (pb + 128)] : 0.0;
+            const double a3 = (rok && pb + 192 < n) ? A[r + (long)n * (pb + 192)] : 0.0;
+            Lc[pb * QT_LSTRIDE + r] = a1;
+            x2[k] = a2;
+            x3[k] = a3;
+            n0 += a0 * a0; n1 += a1 * a1; n2 += a2 * a2; n3 += a3 * a3;
+        }
+        nrmp[rg * 256 + pb] = n0;
+        nrmp[rg * 256 + pb + 64] = n1;
+        nrmp[rg * 256 + pb + 128] = n2;
+        nrmp[rg * 256 + pb + 192] = n3;
+    }
+    if (tid < 256) pv[tid] = tid;
+    __syncthreads();
+
+    // eight regions of 32 steps, each with its compile-time first live row block
+#define QT_REGION(REG)                                             \
+    for (int j = 32 * (REG); j < nsteps && j < 32 * (REG) + 32; ++j) \
+        qt_step<(REG)>(n, j, A, tau, Lc, colP, colJ, vbuf, nrmp, dummy, pv, cand_v, cand_i, x2, x3);
+    QT_REGION(0) QT_REGION(1) QT_REGION(2) QT_REGION(3) QT_REGION(4) QT_REGION(5) QT_REGION(6) QT_REGION(7)
+#undef QT_REGION
+    if (tid < n) piv[tid] = pv[tid];
+}
+
 hipError_t launch_qr_pivot(int n, int n_units, double *A, long strideA, double *tau, int *pivot, hipStream_t s)
 {
     if (n > 1024) return hipErrorInvalidValue;
+    static const bool no_tile = getenv("DQMC_QR_STREAM") != nullptr;
+    if (n > 128 && n <= 256 && !no_tile) {
+        const size_t lds_t = (64 * QT_LSTRIDE + 3 * 256 + 8 * QT_VS + 8 * 256) * sizeof(double) + 256 * sizeof(int);
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void *)qr_tile256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds_t);
+            attr_set = true;
+        }
+        static const char *dbg = getenv("DQMC_QR_STEPS");
+        const int nsteps = dbg ? (atoi(dbg) < n ? atoi(dbg) : n) : n;
+        hipLaunchKernelGGL(qr_tile256_kernel, dim3(n_units), dim3(QT_THREADS), lds_t, s, n, nsteps, A, strideA, tau, pivot);
+        return hipGetLastError();
+    }
     const size_t lds = 2 * 1024 * sizeof(double);
     dim3 grid(n_units), block(QR_THREADS);
 #define QR_LAUNCH(Q, UC) hipLaunchKernelGGL((qr_pivot_kernel<Q, UC>), grid, block, lds, s, n, A, strideA, tau, pivot)
