@@ -594,10 +594,103 @@ __global__ __launch_bounds__(256) void trsm_kernel(int n, const double *__restri
     }
 }
 
+// ---------------------------------------------------------------------------
+// MFMA-blocked variant for n <= 256.  X T = O with T upper triangular is solved by column blocks
+// of 16: the contribution of all previous blocks is one 32 x 16 x j0 product on
+// v_mfma_f64_16x16x4_f64 (X slab from LDS, the T panel staged to LDS), followed by a 16-step
+// substitution inside the block (one lane per row, the block's solved values in registers).
+// One workgroup (2 waves) owns a 32-row slab; 8 slabs x units fill the chip.
+typedef double d4_t __attribute__((ext_vector_type(4)));
+constexpr int TM_XS = 40;    // LDS stride of an X column (32 rows + pad: conflict-free MFMA operand reads)
+constexpr int TM_TS = 258;   // LDS stride of a T panel column (2*TS = 4 mod 64 dwords: conflict-free)
+
+__global__ __launch_bounds__(128) void trsm_mfma_kernel(int n, const double *__restrict__ Aall, long sA,
+                                                       const double *__restrict__ Tall, long sT,
+                                                       const int *__restrict__ pivall,
+                                                       const double *__restrict__ dmulall, long sV,
+                                                       double *__restrict__ Oall, long sO, int slabs)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double *Xs = sm;                   // [256][TM_XS]
+    double *Tp = Xs + 256 * TM_XS;     // [16][TM_TS]  panel T[0 : j0+16, j0 : j0+16], column c at Tp + c*TM_TS
+    double *rd = Tp + 16 * TM_TS;      // [16] reciprocal diagonal (or dmul)
+    const int unit = blockIdx.x / slabs, row0 = (blockIdx.x % slabs) * 32;
+    const double *__restrict__ A = Aall + (long)unit * sA;
+    const double *__restrict__ T = Tall + (long)unit * sT;
+    const int *__restrict__ piv = pivall ? pivall + (long)unit * n : nullptr;
+    const double *__restrict__ dmul = dmulall ? dmulall + (long)unit * sV : nullptr;
+    double *__restrict__ O = Oall + (long)unit * sO;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+
+    for (int idx = tid; idx < n * 32; idx += 128) {
+        const int j = idx >> 5, r = idx & 31, row = row0 + r;
+        const int pj = piv ? piv[j] : j;
+        Xs[j * TM_XS + r] = row < n ? A[row + (long)n * pj] : 0.0;
+    }
+    const int nblk = (n + 15) >> 4;
+    for (int J = 0; J < nblk; ++J) {
+        const int j0 = J << 4;
+        __syncthreads();  // previous block's panel no longer read; first pass: Xs complete
+        {   // stage the panel: thread (c = tid >> 3) walks k = (tid & 7) + 8 i over 0 .. j0 + c
+            const int c = tid >> 3, col = j0 + c;
+            for (int k = tid & 7; k < j0 + 16; k += 8)
+                Tp[c * TM_TS + k] = (col < n && k <= col) ? T[k + (long)n * col] : 0.0;
+            if (tid < 16) {
+                const int cc = j0 + tid;
+                rd[tid] = cc < n ? (dmul ? dmul[cc] : 1.0 / T[cc + (long)n * cc]) : 0.0;
+            }
+        }
+        __syncthreads();
+        // acc[i = lq + 4 r][c = li] = sum_{k < j0} X[16 w + i, k] T[k, j0 + c]
+        d4_t acc = {0.0, 0.0, 0.0, 0.0};
+        for (int kk = 0; kk < j0; kk += 4) {
+            const double a = Xs[(kk + lq) * TM_XS + 16 * w + li];
+            const double b = Tp[li * TM_TS + kk + lq];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Xs[(j0 + li) * TM_XS + 16 * w + lq + 4 * r] -= acc[r];
+        // substitution inside the block: lane = row (the wave's own 16 rows; LDS ops of one wave are ordered)
+        if (lane < 16) {
+            double xs[16];
+            const int row = 16 * w + lane;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                double x = Xs[(j0 + c) * TM_XS + row];
+#pragma unroll
+                for (int c2 = 0; c2 < c; ++c2) x -= xs[c2] * Tp[c * TM_TS + j0 + c2];
+                x *= rd[c];
+                xs[c] = x;
+                Xs[(j0 + c) * TM_XS + row] = x;
+            }
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < n * 32; idx += 128) {
+        const int j = idx >> 5, r = idx & 31, row = row0 + r;
+        if (row < n) O[row + (long)n * j] = Xs[j * TM_XS + r];
+    }
+}
+
 hipError_t launch_trsm_right_upper(int n, int n_units, const double *A, long sA, const double *T, long sT,
                                    const int *pivot, const double *dmul, long sV, double *Out, long sO,
                                    hipStream_t s)
 {
+    static const bool no_mfma = getenv("DQMC_TRSM_SIMPLE") != nullptr;
+    if (n <= 256 && !no_mfma) {
+        const int slabs = (n + 31) / 32;
+        const size_t lds = (256 * TM_XS + 16 * TM_TS + 16) * sizeof(double);
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void *)trsm_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(trsm_mfma_kernel, dim3(n_units * slabs), dim3(128), lds, s, n, A, sA, T, sT, pivot, dmul,
+                           sV, Out, sO, slabs);
+        return hipGetLastError();
+    }
     // slab height: largest of 64/32/16 whose LDS image fits
     const size_t budget = 150 * 1024;
     auto need = [&](int rs) { return ((size_t)n * rs + ((n + 63) & ~63) + 256) * sizeof(double); };
