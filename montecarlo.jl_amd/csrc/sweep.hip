@@ -92,6 +92,8 @@ __global__ __launch_bounds__(MAXT) void sweep_chunk_kernel(int n, int nb, int mo
         ul[tid] = rs.uniforms ? (d < rs.n_uniforms ? rs.uniforms[d] : 2.0) : philox_uniform(rs.seed, d);
     }
     int ndraw = 0, nneg = 0, exhausted = 0, cnt = 0;
+    const double g0 = sc.gamma[0], g1 = sc.gamma[1], e0 = sc.ebos[0], e1 = sc.ebos[1];
+    const double du0 = sc.dup[0], du1 = sc.dup[1], dd0 = sc.ddn[0], dd1 = sc.ddn[1];
 
     // G0[:, site] and G0[site, :] for one group of sites, prefetched one group ahead
     double colr[SW_GROUP], rowr[SW_GROUP], coln[SW_GROUP], rown[SW_GROUP];
@@ -118,14 +120,14 @@ __global__ __launch_bounds__(MAXT) void sweep_chunk_kernel(int n, int nb, int mo
                 const double d0 = dg[s];
                 double detratio, p, x0, x1 = 0.0;
                 if (model == 0) {  // HubbardModelAttractive.jl:113-127
-                    const double gamma = sc.gamma[ci];
+                    const double gamma = ci ? g1 : g0;
                     const double r = 1.0 + gamma * (1.0 - d0);
                     detratio = r * r;
-                    p = sc.ebos[ci] * detratio;
+                    p = (ci ? e1 : e0) * detratio;
                     x0 = gamma / r;  // Attractive.jl:149: x = gamma / (1 + gamma*IG[i])
                 } else {           // HubbardModelRepulsive.jl:128-156,174-191
                     const double d1 = dg[KD + s];
-                    const double D0 = sc.dup[ci], D1 = sc.ddn[ci];
+                    const double D0 = ci ? du1 : du0, D1 = ci ? dd1 : dd0;
                     const double R0 = 1.0 + D0 * (1.0 - d0), R1 = 1.0 + D1 * (1.0 - d1);
                     detratio = R0 * R1;
                     p = detratio;
