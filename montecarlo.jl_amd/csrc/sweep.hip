@@ -52,7 +52,7 @@ constexpr int SW_GROUP = 8;  // sites per unrolled group (static register indice
 //   dg[2][KD]          current G[i,i] of the chunk's sites
 //   ul[KD]             the uniforms this chunk may consume, in draw order
 //   negv[KD]           negative determinant ratios met (sign-problem statistics)
-//   cs[KD] (int)       HS field of the chunk's sites
+//   cs[KD], flip[KD] (int)  HS field of the chunk's sites at entry / accepted flags
 template <int KD, int MAXT>
 __global__ __launch_bounds__(MAXT) void sweep_chunk_kernel(int n, int nb, int model, double *__restrict__ Gall,
                                                           long strideG, int8_t *__restrict__ conf_slice,
@@ -69,6 +69,7 @@ __global__ __launch_bounds__(MAXT) void sweep_chunk_kernel(int n, int nb, int mo
     double *ul = dg + 2 * KD;
     double *negv = ul + KD;
     int *cs = (int *)(negv + KD);
+    int *flip = cs + KD;               // [KD] accepted sites (field is flipped at write-back)
 
     const int w = blockIdx.x;
     const int tid = threadIdx.x;
@@ -85,6 +86,7 @@ __global__ __launch_bounds__(MAXT) void sweep_chunk_kernel(int n, int nb, int mo
     const bool in_chunk = active && sl >= 0 && sl < nsites;
     if (in_chunk) dg[b * KD + sl] = G[t + (long)n * t];
     const WalkerRng rs = rngs[w];
+    if (tid < KD) flip[tid] = 0;
     if (tid < nsites) {
         cs[tid] = cw[site0 + tid];
         // the k-th uniform consumed by this chunk, whichever site consumes it (DQMC.jl:573)
@@ -161,7 +163,9 @@ __global__ __launch_bounds__(MAXT) void sweep_chunk_kernel(int n, int nb, int mo
                     usb[j * npad + t] = newU;
                     vsb[j * npad + t] = newV;
                     if (in_chunk && sl > s) dg[b * KD + sl] += newU * newV;  // sites <= s are done
-                    if (tid == 0) cs[s] = -c;  // flipped field, written back after the site loop
+                    // cs[s] itself must stay intact: waves drift apart between barriers (a rejected
+                    // site has none) and a slower wave may not have read it yet for ITS proposal
+                    if (tid == 0) flip[s] = 1;
                     ++cnt;
                     __syncthreads();
                 }
@@ -178,7 +182,7 @@ __global__ __launch_bounds__(MAXT) void sweep_chunk_kernel(int n, int nb, int mo
             VTo[t + (long)n * m] = m < cnt ? vsb[m * npad + t] : 0.0;
         }
     }
-    if (tid < nsites) cw[site0 + tid] = (int8_t)cs[tid];
+    if (tid < nsites) cw[site0 + tid] = (int8_t)(flip[tid] ? -cs[tid] : cs[tid]);
     if (tid == 0) {
         for (int k = 0; k < nneg; ++k) magstats_push(stats[w].negative_probability, negv[k]);
         rngs[w].draw = rs.draw + (unsigned long long)ndraw;
@@ -208,7 +212,7 @@ hipError_t launch_sweep_chunk(int n, int nb, int n_walkers, int model, double *G
     dim3 grid(n_walkers), block(threads);
     static const char *dbg = getenv("DQMC_DEBUG_SWEEP");
     if (dbg) nsites = atoi(dbg) < nsites ? atoi(dbg) : nsites;
-    const size_t lds = ((size_t)nb * 2 * kd * npad + 5 * kd) * sizeof(double) + 64;
+    const size_t lds = ((size_t)nb * 2 * kd * npad + 6 * kd) * sizeof(double) + 64;
 #define SW_LAUNCH(KD, MT)                                                                                       \
     do {                                                                                                        \
         static bool attr_set = false;                                                                           \

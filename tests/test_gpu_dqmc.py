@@ -115,3 +115,33 @@ def test_true_greens_and_calculate_at(gpu, O):
     for k in (0, 1, 4, 5, 9, 10):
         assert relerr(mc.calculate_greens(k)[0], refs[0].calculate_greens_at(k)[0]) < TOL
     mc.close()
+
+
+def test_cfg4_repulsive_shape(gpu, O):
+    """BASELINE config 4 shape: repulsive 16x16, beta=8 (two 256x256 blocks sharing the HS field),
+    one walker: prepare + a quarter sweep against the oracle"""
+    mc, refs = make_pair(gpu, O, 16, "repulsive", 8.0, n_walkers=1)
+    mc.prepare(); refs[0].prepare()
+    compare(mc, refs)
+    for _ in range(40):
+        mc.update(); refs[0].update()
+    compare(mc, refs)
+    a, st = mc.analysis(0), refs[0].stats()
+    assert (a.prop_local, a.acc_local) == (st.prop_local, st.acc_local)
+    mc.close()
+
+
+def test_cfg5_shape_n576(gpu, O):
+    """BASELINE config 5 lattice (24x24, n=576, dtau=0.05) at a short beta: exercises the n > 256
+    kernel paths (streaming QR, LDS-slab TRSM, 8-site sweep chunks)"""
+    model = gpu.HubbardModelAttractive(24, 2)
+    mc = gpu.DQMC(model, beta=1.0, delta_tau=0.05, n_walkers=1, seed=7)
+    o = O.OracleDQMC(24, "attractive", beta=1.0, delta_tau=0.05)
+    o.set_conf(mc.conf(0)); o.seed(mc.seeds[0])
+    mc.prepare(); o.prepare()
+    assert relerr(mc.greens_eff(0)[0], o.greens_eff()[0]) < TOL
+    for _ in range(3):
+        mc.update(); o.update()
+    assert np.array_equal(mc.conf(0), o.conf())
+    assert relerr(mc.greens_eff(0)[0], o.greens_eff()[0]) < TOL
+    mc.close()
