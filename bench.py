@@ -141,6 +141,17 @@ def main():
     # 6K per sweep, formed here with compact-WY GEMMs)
     gemm_alg = F["gemm"] + F["rank1"] + (4.0 / 3.0) * n ** 3 * 6 * K
     gemm_ms, gemm_launches = tim["gemm"]
+    # HBM-side traffic of one full GEMM launch: PMC passes cannot run inside this process; the
+    # number comes from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE profile (gfx950 x2
+    # FETCH correction applied there), see profiles/*_pmc_gemm.json
+    traffic = None
+    try:
+        import glob
+        pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_gemm.json")))
+        if pm and args.walkers == WALKERS_PER_GPU:
+            traffic = json.load(open(pm[-1]))["traffic_bytes_per_launch"]
+    except Exception:
+        traffic = None
     achieved = gemm_alg * args.walkers * t_steps / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     out = {
         "metric": "DQMC sweeps/sec, 16x16 Hubbard beta=8 dtau=0.1; achieved % fp64 MFMA roofline",
@@ -152,7 +163,8 @@ def main():
                    "walkers_per_gpu": args.walkers, "parallelism": "walkers sharded, %d rank(s)" % n_gpus,
                    "acceptance_rate": acc_rate},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
+                     "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
+                     "traffic_note": "bytes per full 256^3 x 32 GEMM launch, from profiles/*_pmc_gemm.json",
                      "kernel": "gemm_kernel (v_mfma_f64_16x16x4_f64)", "launches_per_sweep": gemm_launches / t_steps,
                      "avg_launch_us": gemm_ms * 1e3 / max(1, gemm_launches)},
         "whole_sweep": {"algorithmic_gflop_per_walker_sweep": F["total"] / 1e9,
