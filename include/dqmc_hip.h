@@ -92,6 +92,11 @@ int dqmc_device_count(void);
 /* mc.conf (HubbardModel.jl:4-5,46-48); conf is n_sites x slices Int8 */
 int dqmc_set_conf(dqmc_handle *h, int32_t walker, const int8_t *conf);
 int dqmc_get_conf(dqmc_handle *h, int32_t walker, int8_t *conf);
+/* compress(mc, model, conf) = BitArray(conf .== 1) and decompress = 2c .- 1 (HubbardModel.jl:56-59,
+ * used by ConfigRecorder, src/configurations.jl:24-43): the chunks of Julia's BitArray, element i
+ * (1-based column-major) in bit (i-1)%64 of chunk (i-1)/64; ceil(n_sites*slices/64) chunks */
+int dqmc_get_conf_bits(dqmc_handle *h, int32_t walker, uint64_t *chunks);
+int dqmc_set_conf_bits(dqmc_handle *h, int32_t walker, const uint64_t *chunks);
 /* RNG feeding `rand() < p` (DQMC.jl:573).  Test mode: a host-supplied uniform
  * stream consumed with the reference's conditional rule (only when p <= 1). */
 int dqmc_set_uniforms(dqmc_handle *h, int32_t walker, const double *u, size_t n);
@@ -133,6 +138,9 @@ int dqmc_get_greens(dqmc_handle *h, int32_t walker, double *out);
  * walkers, returns the chosen walker's G.  Overwrites Ul..Tr, curr_U, tmp1/2
  * like the reference; does not touch mc.s.greens or the stack slots. */
 int dqmc_calculate_greens_at(dqmc_handle *h, int32_t walker, int32_t slice, double *out);
+/* the per-configuration step of replay!(mc) (DQMC.jl:647-653): calculate_greens(mc, slice) from
+ * scratch into mc.s.greens for every walker (replay! uses slice = 0), current_slice <- 1 */
+int dqmc_replay_greens(dqmc_handle *h, int32_t slice);
 /* wrap_greens!(mc, mc.s.greens, slice, direction) on all walkers (stack.jl:491-500) */
 int dqmc_wrap_greens(dqmc_handle *h, int32_t slice, int32_t direction);
 

@@ -5,6 +5,8 @@ Python here is host plumbing only: lattice/model construction, loop control and 
 ctypes binding of libdqmc_hip.so.  All numerics run in hand-written gfx950 kernels;
 there is no CPU fallback (importing without the built library raises)."""
 from ._lib import DQMCError, lib  # noqa: F401
+from .configurations import (CompressedConf, ConfigRecorder, Discarder, compress,  # noqa: F401
+                             decompress)
 from .lattices import Chain, SquareLattice, build_checkerboard  # noqa: F401
 from .models import (HubbardModel, HubbardModelAttractive, HubbardModelRepulsive,  # noqa: F401
                      rand_conf)

@@ -52,6 +52,8 @@ SIGNATURES = {
     "dqmc_device_count": (C.c_int, []),
     "dqmc_set_conf": (C.c_int, [_H, C.c_int32, C.c_void_p]),
     "dqmc_get_conf": (C.c_int, [_H, C.c_int32, C.c_void_p]),
+    "dqmc_get_conf_bits": (C.c_int, [_H, C.c_int32, C.POINTER(C.c_uint64)]),
+    "dqmc_set_conf_bits": (C.c_int, [_H, C.c_int32, C.POINTER(C.c_uint64)]),
     "dqmc_set_uniforms": (C.c_int, [_H, C.c_int32, _dp, C.c_size_t]),
     "dqmc_seed": (C.c_int, [_H, C.c_int32, C.c_uint64]),
     "dqmc_uniforms_used": (C.c_int, [_H, C.c_int32, C.POINTER(C.c_uint64)]),
@@ -68,6 +70,7 @@ SIGNATURES = {
     "dqmc_set_greens_eff": (C.c_int, [_H, C.c_int32, _dp]),
     "dqmc_get_greens": (C.c_int, [_H, C.c_int32, _dp]),
     "dqmc_calculate_greens_at": (C.c_int, [_H, C.c_int32, C.c_int32, _dp]),
+    "dqmc_replay_greens": (C.c_int, [_H, C.c_int32]),
     "dqmc_wrap_greens": (C.c_int, [_H, C.c_int32, C.c_int32]),
     "dqmc_get_stats": (C.c_int, [_H, C.c_int32, C.POINTER(Stats)]),
     "dqmc_accumulate_greens": (C.c_int, [_H]),

@@ -759,11 +759,9 @@ int dqmc_get_greens(dqmc_handle *h, int32_t w, double *out)
     return DQMC_OK;
 }
 
-// calculate_greens(mc, slice) (stack.jl:422-480)
-int dqmc_calculate_greens_at(dqmc_handle *h, int32_t w, int32_t slice, double *out)
+// calculate_greens(mc, slice, output) (stack.jl:422-480) for every walker of the handle
+static int calculate_greens_from_scratch(dqmc_handle *h, int slice, double *output)
 {
-    ENTER(h); WALKER_OK(h, w);
-    if (slice < 0 || slice > h->M) return fail(h, DQMC_ERR_INVALID, "slice out of range 0..slices");
     const int n = h->n, M = h->M, s = h->s;
     // right factor: Ur,Dr,Tr = B(slice+1)' ... B(M)'
     CHK(set_identity(h, h->bufA)); CHK(set_identity(h, h->Ur)); CHK(set_ones(h, h->Dr)); CHK(set_identity(h, h->Tr));
@@ -811,10 +809,56 @@ int dqmc_calculate_greens_at(dqmc_handle *h, int32_t w, int32_t slice, double *o
         CHK(copy_mat(h, h->tmp1, h->Tl));
         CHK(run_gemm(h, gemm_base(h, U_(h, h->tmp2), 0, U_(h, h->tmp1), 0, h->Tl)));
     }
-    CHK(calculate_greens(h, h->greens_temp));
+    CHK(calculate_greens(h, output));
+    return 0;
+}
+int dqmc_calculate_greens_at(dqmc_handle *h, int32_t w, int32_t slice, double *out)
+{
+    ENTER(h); WALKER_OK(h, w);
+    if (slice < 0 || slice > h->M) return fail(h, DQMC_ERR_INVALID, "slice out of range 0..slices");
+    CHK(calculate_greens_from_scratch(h, slice, h->greens_temp));
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(out, h->greens_temp + (size_t)w * h->nb * h->nn, sizeof(double) * h->nb * h->nn,
                      hipMemcpyDeviceToHost));
+    return DQMC_OK;
+}
+// the per-configuration step of replay!(mc) (DQMC.jl:651-653): calculate_greens(mc, slice) into
+// mc.s.greens for every walker; current_slice is set like replay! does (DQMC.jl:647)
+int dqmc_replay_greens(dqmc_handle *h, int32_t slice)
+{
+    ENTER(h);
+    if (slice < 0 || slice > h->M) return fail(h, DQMC_ERR_INVALID, "slice out of range 0..slices");
+    CHK(calculate_greens_from_scratch(h, slice, h->greens));
+    h->current_slice = 1;
+    h->prepared = true;
+    return dqmc_synchronize(h);
+}
+// compress(mc, model, conf) / decompress (HubbardModel.jl:56-59): Julia BitArray chunks
+int dqmc_get_conf_bits(dqmc_handle *h, int32_t w, uint64_t *chunks)
+{
+    ENTER(h); WALKER_OK(h, w);
+    const size_t sz = (size_t)h->N * h->M, nch = (sz + 63) / 64;
+    unsigned long long *d = nullptr;
+    HIPCHK(hipMalloc((void **)&d, nch * sizeof(unsigned long long)));
+    hipError_t e1 = launch_conf_pack(h->conf + (size_t)w * sz, sz, d, h->stream);
+    hipError_t e2 = e1 == hipSuccess ? hipStreamSynchronize(h->stream) : e1;
+    hipError_t e3 = e2 == hipSuccess ? hipMemcpy(chunks, d, nch * sizeof(unsigned long long), hipMemcpyDeviceToHost) : e2;
+    (void)hipFree(d);
+    HIPCHK(e3);
+    return DQMC_OK;
+}
+int dqmc_set_conf_bits(dqmc_handle *h, int32_t w, const uint64_t *chunks)
+{
+    ENTER(h); WALKER_OK(h, w);
+    const size_t sz = (size_t)h->N * h->M, nch = (sz + 63) / 64;
+    unsigned long long *d = nullptr;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMalloc((void **)&d, nch * sizeof(unsigned long long)));
+    hipError_t e1 = hipMemcpy(d, chunks, nch * sizeof(unsigned long long), hipMemcpyHostToDevice);
+    hipError_t e2 = e1 == hipSuccess ? launch_conf_unpack(d, sz, h->conf + (size_t)w * sz, h->stream) : e1;
+    hipError_t e3 = e2 == hipSuccess ? hipStreamSynchronize(h->stream) : e2;
+    (void)hipFree(d);
+    HIPCHK(e3);
     return DQMC_OK;
 }
 

@@ -329,4 +329,33 @@ hipError_t launch_accumulate(int n, int nb, int n_walkers, const double *G, long
     return hipGetLastError();
 }
 
+// compress(mc, model, conf) = BitArray(conf .== 1) (HubbardModel.jl:56-59): Julia's BitArray keeps
+// element i (1-based, column-major) in bit (i-1) % 64 of chunk (i-1) / 64.  One wave packs one chunk.
+__global__ void conf_pack_kernel(const int8_t *__restrict__ conf, size_t n_elem, unsigned long long *__restrict__ chunks)
+{
+    const size_t chunk = blockIdx.x * (size_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
+    const size_t nchunks = (n_elem + 63) >> 6;
+    if (chunk >= nchunks) return;
+    const size_t i = chunk * 64 + (threadIdx.x & 63);
+    const unsigned long long b = __ballot(i < n_elem && conf[i] == 1);
+    if ((threadIdx.x & 63) == 0) chunks[chunk] = b;
+}
+// decompress: CT(2c .- 1)
+__global__ void conf_unpack_kernel(const unsigned long long *__restrict__ chunks, size_t n_elem, int8_t *__restrict__ conf)
+{
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n_elem) conf[i] = ((chunks[i >> 6] >> (i & 63)) & 1ull) ? 1 : -1;
+}
+hipError_t launch_conf_pack(const int8_t *conf, size_t n_elem, unsigned long long *chunks, hipStream_t s)
+{
+    const size_t nchunks = (n_elem + 63) >> 6;
+    hipLaunchKernelGGL(conf_pack_kernel, dim3((unsigned)((nchunks + 3) / 4)), dim3(256), 0, s, conf, n_elem, chunks);
+    return hipGetLastError();
+}
+hipError_t launch_conf_unpack(const unsigned long long *chunks, size_t n_elem, int8_t *conf, hipStream_t s)
+{
+    hipLaunchKernelGGL(conf_unpack_kernel, dim3((unsigned)((n_elem + 255) / 256)), dim3(256), 0, s, chunks, n_elem, conf);
+    return hipGetLastError();
+}
+
 }  // namespace dqmc

@@ -12,6 +12,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import check, dptr, i64ptr, lib
+from .configurations import CompressedConf, ConfigRecorder
 from .models import rand_conf
 
 
@@ -134,6 +135,20 @@ class DQMC:
         self._c(lib().dqmc_get_conf(self._h, walker, c.ctypes.data))
         return c
 
+    def conf_bits(self, walker=0):
+        """compress(mc, model, conf(mc)) packed on the device (HubbardModel.jl:56-59)"""
+        n = (self.N * self.p.slices + 63) // 64
+        ch = np.zeros(n, dtype=np.uint64)
+        self._c(lib().dqmc_get_conf_bits(self._h, walker, ch.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return CompressedConf(ch, (self.N, self.p.slices))
+
+    def set_conf_bits(self, walker, cc):
+        """mc.conf = decompress(mc, model, c), unpacked on the device"""
+        if cc.shape != (self.N, self.p.slices):
+            raise ValueError("compressed configuration has the wrong shape")
+        ch = np.ascontiguousarray(cc.chunks, dtype=np.uint64)
+        self._c(lib().dqmc_set_conf_bits(self._h, walker, ch.ctypes.data_as(C.POINTER(C.c_uint64))))
+
     def seed(self, walker, seed):
         self._c(lib().dqmc_seed(self._h, walker, seed))
 
@@ -187,7 +202,38 @@ class DQMC:
     def synchronize(self):
         self._c(lib().dqmc_synchronize(self._h))
 
-    def run(self, verbose=False, on_measure=None):
+    def replay_greens(self, slice_=0):
+        """calculate_greens(mc, slice) into mc.s.greens for every walker (DQMC.jl:651-652)"""
+        self._c(lib().dqmc_replay_greens(self._h, slice_))
+
+    def replay(self, configurations, measure_rate=1):
+        """replay!(mc, configurations) (DQMC.jl:605-697): the recorded configurations are decompressed
+        on the device, `n_walkers` at a time, the Green's function is rebuilt from scratch at slice 0
+        (calculate_greens(mc, 0), DQMC.jl:652) and the measurement sums are accumulated.
+        Returns the accumulator vector (layout of include/dqmc_hip.h)."""
+        cfgs = list(configurations)[::measure_rate]
+        self.reset_accumulators()
+        W, n, B = self.n_walkers, self.N, self.nb
+        tail = np.zeros(self.accumulator_size())
+        for i0 in range(0, len(cfgs), W):
+            batch = cfgs[i0:i0 + W]
+            for w in range(W):  # a short last batch repeats its last configuration in the idle walkers
+                self.set_conf_bits(w, batch[min(w, len(batch) - 1)])
+            self.replay_greens(0)
+            if len(batch) == W:
+                self.accumulate_greens()
+            else:  # partial batch: only the filled walkers count
+                for w in range(len(batch)):
+                    G = self.greens(w)
+                    g = np.concatenate([x.reshape(-1, order="F") for x in G])
+                    tail[:B * n * n] += g
+                    tail[B * n * n:2 * B * n * n] += g * g
+                    for b in range(B):
+                        tail[2 * B * n * n + b * n:2 * B * n * n + (b + 1) * n] += 1.0 - np.diag(G[b])
+                    tail[-1] += 1
+        return self.accumulators() + tail
+
+    def run(self, verbose=False, on_measure=None, recorder=None):
         """run!(mc) (DQMC.jl:369-515) without the host-side measurement framework: the
         true Green's function is accumulated on the device every `measure_rate`-th sweep
         after thermalization, at current_slice == 1 && direction == +1 (DQMC.jl:425-436)."""
@@ -199,6 +245,8 @@ class DQMC:
             for _ in range(2 * self.p.slices):
                 self._c(lib().dqmc_update(self._h))
                 cs, d = self._state()
+                if cs == 1 and d == 1 and i > self.p.thermalization and recorder is not None:
+                    recorder.push(self, i)  # push!(mc.configs, mc, mc.model, i) (DQMC.jl:430)
                 if cs == 1 and d == 1 and i > self.p.thermalization and i % self.p.measure_rate == 0:
                     self._c(lib().dqmc_accumulate_greens(self._h))
                     if on_measure is not None:

@@ -104,3 +104,18 @@ def test_sharding(mc_amd):
     assert first == 96 and ids == list(range(96, 128))
     seeds = [s for r in range(4) for s in mc_amd.walker_seeds(123, r, 4, 2)]
     assert seeds == list(range(123, 131))
+
+
+def test_compress_layout_host(mc_amd):
+    """BitArray(conf .== 1): element i (1-based, column-major) -> bit (i-1) % 64 of chunk (i-1) / 64"""
+    rng = np.random.Generator(np.random.Philox(key=3))
+    c = mc_amd.rand_conf(rng, 9, 15)   # 135 elements: ragged last chunk
+    cc = mc_amd.compress(c)
+    assert cc.chunks.dtype == np.uint64 and cc.chunks.size == 3
+    flat = c.reshape(-1, order="F")
+    for i in range(135):
+        assert ((int(cc.chunks[i // 64]) >> (i % 64)) & 1) == (flat[i] == 1)
+    assert int(cc.chunks[2]) >> (135 - 128) == 0
+    assert np.array_equal(mc_amd.decompress(cc), c)
+    r = mc_amd.ConfigRecorder(rate=3)
+    assert len(r) == 0 and len(mc_amd.Discarder()) == 0
