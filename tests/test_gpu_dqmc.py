@@ -145,3 +145,26 @@ def test_cfg5_shape_n576(gpu, O):
     assert np.array_equal(mc.conf(0), o.conf())
     assert relerr(mc.greens_eff(0)[0], o.greens_eff()[0]) < TOL
     mc.close()
+
+
+def test_ed_known_answer_on_gpu(gpu):
+    """test/ED/ED_tests.jl:91-176 on the product path: mean Green's function of the 2x2 Hubbard
+    models (U=1, t=1, beta=1, dtau=0.1, safe_mult=5; mu=1 for the attractive model) from run()
+    against exact diagonalisation (fixture tests/golden/ed_hubbard_2x2.json), atol = rtol = 2*dtau^2"""
+    import json, os
+    ed = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ed_hubbard_2x2.json")))
+    for model, key in ((gpu.HubbardModelRepulsive(2, 2, U=1.0), "repulsive_U1_t1"),
+                       (gpu.HubbardModelAttractive(2, 2, U=1.0, mu=1.0), "attractive_U1_mu1_t1")):
+        mc = gpu.DQMC(model, beta=1.0, safe_mult=5, n_walkers=64, seed=2024, thermalization=100, sweeps=150,
+                      measure_rate=1)
+        mc.run()
+        res = mc.unpack_accumulators(mc.accumulators())
+        assert res["count"] == 64 * 150
+        Ged = np.array(ed[key])
+        for b in range(mc.nb):
+            ref = Ged[4 * b:4 * b + 4, 4 * b:4 * b + 4]
+            assert np.all(np.abs(res["G"][b] - ref) <= 0.02 + 0.02 * np.abs(ref)), (key, b)
+            assert np.all(np.abs(res["occupation"][b] - (1 - np.diag(ref))) <= 0.02 + 0.02 * np.abs(1 - np.diag(ref)))
+        a = mc.analysis(0)
+        assert a.prop_local == 250 * 20 * 4 and a.propagation_error.count == 0
+        mc.close()
