@@ -53,7 +53,8 @@ constexpr int SW_GROUP = 8;  // sites per unrolled group (static register indice
 //   ul[KD]             the uniforms this chunk may consume, in draw order
 //   negv[KD]           negative determinant ratios met (sign-problem statistics)
 //   cs[KD], flip[KD] (int)  HS field of the chunk's sites at entry / accepted flags
-template <int KD, int MAXT>
+// NPAD > 0: compile-time row stride of the LDS update vectors (immediate offsets in the slot loop)
+template <int KD, int MAXT, int NPAD>
 __global__ __launch_bounds__(MAXT) void sweep_chunk_kernel(int n, int nb, int model, double *__restrict__ Gall,
                                                           long strideG, int8_t *__restrict__ conf_slice,
                                                           long conf_stride, int site0, int nsites,
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(MAXT) void sweep_chunk_kernel(int n, int nb, int mo
                                                           DevStats *stats, int check_sign)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int npad = (n + 63) & ~63;
+    const int npad = NPAD > 0 ? NPAD : ((n + 63) & ~63);
     double *Us = sm;
     double *Vs = Us + (size_t)nb * KD * npad;
     double *dg = Vs + (size_t)nb * KD * npad;  // [2][KD]
@@ -120,22 +121,23 @@ __global__ __launch_bounds__(MAXT) void sweep_chunk_kernel(int n, int nb, int mo
                 const int c = cs[s];
                 const int ci = c > 0 ? 1 : 0;
                 const double d0 = dg[s];
-                double detratio, p, x0, x1 = 0.0;
+                double detratio, p, x0, x1 = 0.0, r0s = 0.0, r1s = 0.0, d0s = 0.0, d1s = 0.0;
                 if (model == 0) {  // HubbardModelAttractive.jl:113-127
                     const double gamma = ci ? g1 : g0;
                     const double r = 1.0 + gamma * (1.0 - d0);
                     detratio = r * r;
                     p = (ci ? e1 : e0) * detratio;
-                    x0 = gamma / r;  // Attractive.jl:149: x = gamma / (1 + gamma*IG[i])
+                    x0 = gamma;  // numerator; the division by r is off the decision path (done on accept)
+                    x1 = r;
                 } else {           // HubbardModelRepulsive.jl:128-156,174-191
                     const double d1 = dg[KD + s];
                     const double D0 = ci ? du1 : du0, D1 = ci ? dd1 : dd0;
                     const double R0 = 1.0 + D0 * (1.0 - d0), R1 = 1.0 + D1 * (1.0 - d1);
                     detratio = R0 * R1;
                     p = detratio;
-                    const double inv_div = 1.0 / detratio;
-                    x0 = (R1 * inv_div) * D0;
-                    x1 = (R0 * inv_div) * D1;
+                    x0 = R1 * D0;   // numerators only, see the accept branch
+                    x1 = R0 * D1;
+                    r0s = R0; r1s = R1; d0s = D0; d1s = D1;
                 }
                 if (check_sign && detratio < 0.0) {
                     if (tid == 0) negv[nneg] = detratio;
@@ -150,13 +152,42 @@ __global__ __launch_bounds__(MAXT) void sweep_chunk_kernel(int n, int nb, int mo
                 }
                 if (acc) {
                     const int j = __builtin_amdgcn_readfirstlane(cnt);
-                    const double xb = (b == 0) ? x0 : x1;
-                    double cold = colr[q], rowd = rowr[q];
-#pragma unroll 4
-                    for (int m = 0; m < j; ++m) {
-                        cold += usb[m * npad + t] * vsb[m * npad + i];
-                        rowd += usb[m * npad + i] * vsb[m * npad + t];
+                    double xb;
+                    if (model == 0) xb = x0 / x1;  // Attractive.jl:149: x = gamma / (1 + gamma*IG[i])
+                    else {                          // Repulsive.jl:174-191: (R_other * inv_div) * Delta_b
+                        const double inv_div = 1.0 / detratio;
+                        xb = (b == 0) ? (r1s * inv_div) * d0s : (r0s * inv_div) * d1s;
                     }
+                    // four accumulation chains over the slots (even/odd), pointers advanced by the
+                    // (compile-time when NPAD > 0) row stride: LDS reads get immediate offsets
+                    double c0 = colr[q], c1 = 0.0, r0 = rowr[q], r1 = 0.0;
+                    const double *pu_t = usb + t, *pu_i = usb + i, *pv_t = vsb + t, *pv_i = vsb + i;
+                    int m = 0;
+                    for (; m + 8 <= j; m += 8) {  // 32 LDS reads in flight before the first use
+                        double a_[8], b_[8], c_[8], d_[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            a_[e] = pu_t[e * npad]; b_[e] = pv_i[e * npad];
+                            c_[e] = pu_i[e * npad]; d_[e] = pv_t[e * npad];
+                        }
+#pragma unroll
+                        for (int e = 0; e < 8; e += 2) {
+                            c0 += a_[e] * b_[e];         r0 += c_[e] * d_[e];
+                            c1 += a_[e + 1] * b_[e + 1]; r1 += c_[e + 1] * d_[e + 1];
+                        }
+                        pu_t += 8 * npad; pu_i += 8 * npad; pv_t += 8 * npad; pv_i += 8 * npad;
+                    }
+                    for (; m + 2 <= j; m += 2) {
+                        c0 += pu_t[0] * pv_i[0];        r0 += pu_i[0] * pv_t[0];
+                        c1 += pu_t[npad] * pv_i[npad];  r1 += pu_i[npad] * pv_t[npad];
+                        pu_t += 2 * npad; pu_i += 2 * npad; pv_t += 2 * npad; pv_i += 2 * npad;
+                    }
+                    for (; m < j; ++m) {
+                        c0 += pu_t[0] * pv_i[0];
+                        r0 += pu_i[0] * pv_t[0];
+                        pu_t += npad; pu_i += npad; pv_t += npad; pv_i += npad;
+                    }
+                    const double cold = c0 + c1, rowd = r0 + r1;
                     const double ut = ((t == i) ? 1.0 : 0.0) - cold;  // IG = e_i - G[:,i]
                     double newU = -(ut * xb), newV = rowd;
                     if (!active) { newU = 0.0; newV = 0.0; }
@@ -213,25 +244,28 @@ hipError_t launch_sweep_chunk(int n, int nb, int n_walkers, int model, double *G
     static const char *dbg = getenv("DQMC_DEBUG_SWEEP");
     if (dbg) nsites = atoi(dbg) < nsites ? atoi(dbg) : nsites;
     const size_t lds = ((size_t)nb * 2 * kd * npad + 6 * kd) * sizeof(double) + 64;
-#define SW_LAUNCH(KD, MT)                                                                                       \
+#define SW_LAUNCH(KD, MT, NP)                                                                                     \
     do {                                                                                                        \
         static bool attr_set = false;                                                                           \
         if (!attr_set) {                                                                                        \
-            (void)hipFuncSetAttribute((const void *)sweep_chunk_kernel<KD, MT>,                                 \
+            (void)hipFuncSetAttribute((const void *)sweep_chunk_kernel<KD, MT, NP>,                             \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                  \
             attr_set = true;                                                                                    \
         }                                                                                                       \
-        hipLaunchKernelGGL((sweep_chunk_kernel<KD, MT>), grid, block, lds, s, n, nb, model, G, strideG,         \
+        hipLaunchKernelGGL((sweep_chunk_kernel<KD, MT, NP>), grid, block, lds, s, n, nb, model, G, strideG,     \
                            conf_slice, conf_stride, site0, nsites, Uout, VTout, strideUV, sc, rng, stats,       \
                            check_sign);                                                                         \
     } while (0)
-#define SW_BY_THREADS(KD)                          \
-    do {                                           \
-        if (threads <= 256) SW_LAUNCH(KD, 256);    \
-        else if (threads <= 512) SW_LAUNCH(KD, 512); \
-        else SW_LAUNCH(KD, 1024);                  \
+#define SW_BY_THREADS(KD)                             \
+    do {                                              \
+        if (threads <= 256) SW_LAUNCH(KD, 256, 0);    \
+        else if (threads <= 512) SW_LAUNCH(KD, 512, 0); \
+        else SW_LAUNCH(KD, 1024, 0);                  \
     } while (0)
-    if (kd == 32) SW_BY_THREADS(32);
+    // the benchmark shapes (16x16 lattice) get the compile-time stride
+    if (npad == 256 && kd == 32 && threads == 256) SW_LAUNCH(32, 256, 256);
+    else if (npad == 256 && kd == 16 && threads == 512) SW_LAUNCH(16, 512, 256);
+    else if (kd == 32) SW_BY_THREADS(32);
     else if (kd == 16) SW_BY_THREADS(16);
     else if (kd == 8) SW_BY_THREADS(8);
     else SW_BY_THREADS(4);
