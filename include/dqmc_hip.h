@@ -163,6 +163,20 @@ int dqmc_reset_accumulators(dqmc_handle *h);
 int dqmc_get_accumulators(dqmc_handle *h, double *host_out);
 int dqmc_export_accumulators(dqmc_handle *h, void *device_out);
 
+/* ---- equal-time correlation measurements on the device ----------------------
+ * cdc_kernel, sdc_{x,y,z}_kernel over EachSitePairByDistance and m{x,y,z}_kernel over EachSite
+ * (measurements/measurements.jl:51-190, generic.jl:325-330; HubbardModelAttractive.jl:219-246).
+ * dir_of[src + n*trg] (0-based) is the direction index of a pair as produced by
+ * EachSitePairByDistance(lattice) (src/lattices/lattice_iterators.jl:157-190).  Accumulator layout:
+ *   [cdc n_dirs][sdc_x n_dirs][sdc_y n_dirs][sdc_z n_dirs][mx n][my n][mz n][samples]
+ * every pair quantity already divided by n_sites as finish! does (generic.jl:283-286);
+ * dqmc_reset_accumulators clears these sums too. */
+int dqmc_set_pair_directions(dqmc_handle *h, const int32_t *dir_of, int32_t n_dirs);
+int dqmc_accumulate_correlations(dqmc_handle *h);
+int dqmc_correlations_size(dqmc_handle *h, size_t *n_doubles);
+int dqmc_get_correlations(dqmc_handle *h, double *host_out);
+int dqmc_export_correlations(dqmc_handle *h, void *device_out);
+
 /* ---- batched linalg primitives (unit parity with test/slice_matrices.jl) --
  * host in / host out, `batch` independent n x n problems, run on device_id.  */
 /* vmul! family (src/linalg/general.jl:7-56): C = op(A)*op(B); transa/transb 0|1 */

@@ -7,7 +7,8 @@ there is no CPU fallback (importing without the built library raises)."""
 from ._lib import DQMCError, lib  # noqa: F401
 from .configurations import (CompressedConf, ConfigRecorder, Discarder, compress,  # noqa: F401
                              decompress)
-from .lattices import Chain, SquareLattice, build_checkerboard  # noqa: F401
+from . import lattices  # noqa: F401
+from .lattices import Chain, EachSitePairByDistance, SquareLattice, build_checkerboard  # noqa: F401
 from .models import (HubbardModel, HubbardModelAttractive, HubbardModelRepulsive,  # noqa: F401
                      rand_conf)
 from .sharding import reduce_accumulators, walker_range, walker_seeds  # noqa: F401

@@ -78,6 +78,11 @@ SIGNATURES = {
     "dqmc_reset_accumulators": (C.c_int, [_H]),
     "dqmc_get_accumulators": (C.c_int, [_H, _dp]),
     "dqmc_export_accumulators": (C.c_int, [_H, C.c_void_p]),
+    "dqmc_set_pair_directions": (C.c_int, [_H, C.POINTER(C.c_int32), C.c_int32]),
+    "dqmc_accumulate_correlations": (C.c_int, [_H]),
+    "dqmc_correlations_size": (C.c_int, [_H, C.POINTER(C.c_size_t)]),
+    "dqmc_get_correlations": (C.c_int, [_H, _dp]),
+    "dqmc_export_correlations": (C.c_int, [_H, C.c_void_p]),
     "dqmc_vmul": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _dp, _dp, _dp]),
     "dqmc_udt_pivot": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _dp, _dp, _dp, _i64p, C.c_int32]),
     "dqmc_rdivp": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _dp, _dp, _i64p]),

@@ -43,6 +43,11 @@ struct dqmc_handle {
     std::vector<double *> uniforms;  // per walker device arrays
     double *acc = nullptr;
     size_t acc_n = 0;
+    // correlation measurements (EachSitePairByDistance tables set by the host)
+    int n_dirs = 0;
+    int *dir_ptr = nullptr, *pair_src = nullptr, *pair_trg = nullptr;
+    double *corr_per_walker = nullptr, *corr_acc = nullptr;
+    size_t corr_n = 0;
     int current_slice = 0, direction = 0;
     bool prepared = false;
     std::string err;
@@ -897,6 +902,78 @@ int dqmc_accumulate_greens(dqmc_handle *h)
     }
     return DQMC_OK;
 }
+// EachSitePairByDistance(lattice) (lattice_iterators.jl:157-190) as a direction table
+int dqmc_set_pair_directions(dqmc_handle *h, const int32_t *dir_of, int32_t n_dirs)
+{
+    ENTER(h);
+    const int n = h->n;
+    if (!dir_of || n_dirs < 1 || n_dirs > n * n) return fail(h, DQMC_ERR_INVALID, "bad direction table");
+    std::vector<int> ptr(n_dirs + 1, 0), src((size_t)n * n), trg((size_t)n * n);
+    for (int s = 0; s < n; ++s)
+        for (int t = 0; t < n; ++t) {
+            const int d = dir_of[s + (size_t)n * t];
+            if (d < 0 || d >= n_dirs) return fail(h, DQMC_ERR_INVALID, "direction index out of range");
+            ptr[d + 1]++;
+        }
+    for (int d = 0; d < n_dirs; ++d) ptr[d + 1] += ptr[d];
+    std::vector<int> fill(ptr.begin(), ptr.end() - 1);
+    for (int s = 0; s < n; ++s)          // the reference's order inside a direction: src outer, trg inner
+        for (int t = 0; t < n; ++t) {
+            const int d = dir_of[s + (size_t)n * t];
+            src[fill[d]] = s;
+            trg[fill[d]] = t;
+            fill[d]++;
+        }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (!h->pair_src) {
+        CHK(dalloc(h, &h->pair_src, (size_t)n * n));
+        CHK(dalloc(h, &h->pair_trg, (size_t)n * n));
+    }
+    CHK(dalloc(h, &h->dir_ptr, (size_t)n_dirs + 1));
+    h->n_dirs = n_dirs;
+    h->corr_n = 4 * (size_t)n_dirs + 3 * (size_t)n + 1;
+    CHK(dalloc(h, &h->corr_per_walker, (size_t)h->W * 4 * n_dirs));
+    CHK(dalloc(h, &h->corr_acc, h->corr_n));
+    HIPCHK(hipMemcpy(h->dir_ptr, ptr.data(), sizeof(int) * (n_dirs + 1), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->pair_src, src.data(), sizeof(int) * n * n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->pair_trg, trg.data(), sizeof(int) * n * n, hipMemcpyHostToDevice));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return DQMC_OK;
+}
+int dqmc_accumulate_correlations(dqmc_handle *h)
+{
+    ENTER(h); NEED_PREPARED(h);
+    if (!h->n_dirs) return fail(h, DQMC_ERR_STATE, "call dqmc_set_pair_directions first");
+    CHK(true_greens(h, h->greens));
+    {
+        Timed t(h, DQMC_K_MISC);
+        HIPCHK(launch_correlations(h->n, h->nb, h->p.model_kind, h->W, h->tmp2, h->nn, h->dir_ptr, h->pair_src,
+                                   h->pair_trg, h->n_dirs, h->corr_per_walker, h->corr_acc, h->stream));
+    }
+    return DQMC_OK;
+}
+int dqmc_correlations_size(dqmc_handle *h, size_t *n)
+{
+    if (!h || !n) return DQMC_ERR_INVALID;
+    *n = h->corr_n;
+    return DQMC_OK;
+}
+int dqmc_get_correlations(dqmc_handle *h, double *host_out)
+{
+    ENTER(h);
+    if (!h->n_dirs) return fail(h, DQMC_ERR_STATE, "call dqmc_set_pair_directions first");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(host_out, h->corr_acc, h->corr_n * sizeof(double), hipMemcpyDeviceToHost));
+    return DQMC_OK;
+}
+int dqmc_export_correlations(dqmc_handle *h, void *device_out)
+{
+    ENTER(h);
+    if (!h->n_dirs) return fail(h, DQMC_ERR_STATE, "call dqmc_set_pair_directions first");
+    HIPCHK(hipMemcpyAsync(device_out, h->corr_acc, h->corr_n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return DQMC_OK;
+}
 int dqmc_accumulator_size(dqmc_handle *h, size_t *n)
 {
     if (!h || !n) return DQMC_ERR_INVALID;
@@ -907,6 +984,7 @@ int dqmc_reset_accumulators(dqmc_handle *h)
 {
     ENTER(h);
     HIPCHK(hipMemsetAsync(h->acc, 0, h->acc_n * sizeof(double), h->stream));
+    if (h->corr_acc) HIPCHK(hipMemsetAsync(h->corr_acc, 0, h->corr_n * sizeof(double), h->stream));
     return DQMC_OK;
 }
 int dqmc_get_accumulators(dqmc_handle *h, double *host_out)

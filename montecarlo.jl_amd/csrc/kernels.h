@@ -107,6 +107,11 @@ hipError_t launch_prop_check(int n, int nb, int n_walkers, const double *A, cons
 hipError_t launch_accumulate(int n, int nb, int n_walkers, const double *G, long stride_unit,
                              double *acc, hipStream_t s);
 hipError_t launch_mfma_peak(int iters, int blocks, double *sink, hipStream_t s);
+// equal-time correlations (cdc, sdc_x/y/z per direction; mx, my, mz per site), summed over walkers:
+// acc layout [cdc nd][sdc_x nd][sdc_y nd][sdc_z nd][mx n][my n][mz n][count]
+hipError_t launch_correlations(int n, int nb, int model, int n_walkers, const double *G, long stride_unit,
+                               const int *dir_ptr, const int *pair_src, const int *pair_trg, int n_dirs,
+                               double *per_walker, double *acc, hipStream_t s);
 // HS field <-> Julia BitArray chunks (compress / decompress, HubbardModel.jl:56-59)
 hipError_t launch_conf_pack(const int8_t *conf, size_t n_elem, unsigned long long *chunks, hipStream_t s);
 hipError_t launch_conf_unpack(const unsigned long long *chunks, size_t n_elem, int8_t *conf, hipStream_t s);

@@ -363,6 +363,90 @@ hipError_t launch_accumulate(int n, int nb, int n_walkers, const double *G, long
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// Equal-time correlation measurements on the true Green's function:
+// cdc_kernel, sdc_{x,y,z}_kernel over EachSitePairByDistance and m{x,y,z}_kernel over EachSite
+// (src/flavors/DQMC/measurements/measurements.jl:51-190, generic.jl:325-330,
+// attractive overrides HubbardModelAttractive.jl:219-246).  For the repulsive model G is block
+// diagonal (up, down), so every cross-spin element of the reference's 2N x 2N formulas is 0.
+// One workgroup sums one direction of one walker over its pairs in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void corr_pairs_kernel(int n, int nb, int model, const double *__restrict__ G,
+                                                        long stride_unit, const int *__restrict__ dir_ptr,
+                                                        const int *__restrict__ pair_src,
+                                                        const int *__restrict__ pair_trg, int n_dirs,
+                                                        double *__restrict__ per_walker, long per_stride)
+{
+    __shared__ double red[4][256];
+    const int d = blockIdx.x, w = blockIdx.y, tid = threadIdx.x;
+    const double *G1 = G + (long)(w * nb) * stride_unit;
+    const double *G2 = nb == 2 ? G1 + stride_unit : G1;
+    double cdc = 0.0, sx = 0.0, sy = 0.0, sz = 0.0;
+    for (int q = dir_ptr[d] + tid; q < dir_ptr[d + 1]; q += 256) {
+        const int i = pair_src[q], j = pair_trg[q];
+        const double dij = i == j ? 1.0 : 0.0;
+        const double a_ii = G1[i + (long)n * i], a_jj = G1[j + (long)n * j];
+        const double a_ij = G1[i + (long)n * j], a_ji = G1[j + (long)n * i];
+        if (model == 0) {  // HubbardModelAttractive.jl:222-236
+            const double t = 2.0 * (dij - a_ji) * a_ij;
+            cdc += 4.0 * (1.0 - a_ii) * (1.0 - a_jj) + t;
+            sx += t; sy += t; sz += t;
+        } else {
+            const double b_ii = G2[i + (long)n * i], b_jj = G2[j + (long)n * j];
+            const double b_ij = G2[i + (long)n * j], b_ji = G2[j + (long)n * i];
+            // measurements.jl:63-76
+            cdc += (1.0 - a_ii) * (1.0 - a_jj) + (dij - a_ji) * a_ij + (1.0 - a_ii) * (1.0 - b_jj) +
+                   (1.0 - b_ii) * (1.0 - a_jj) + (1.0 - b_ii) * (1.0 - b_jj) + (dij - b_ji) * b_ij;
+            // measurements.jl:150-156 / :167-173 with the cross-spin elements zero
+            const double t = (dij - a_ji) * b_ij + (dij - b_ji) * a_ij;
+            sx += t; sy += t;
+            // measurements.jl:184-189
+            sz += (1.0 - a_ii) * (1.0 - a_jj) + (dij - a_ji) * a_ij - (1.0 - a_ii) * (1.0 - b_jj) -
+                  (1.0 - b_ii) * (1.0 - a_jj) + (1.0 - b_ii) * (1.0 - b_jj) + (dij - b_ji) * b_ij;
+        }
+    }
+    red[0][tid] = cdc; red[1][tid] = sx; red[2][tid] = sy; red[3][tid] = sz;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off)
+            for (int q = 0; q < 4; ++q) red[q][tid] += red[q][tid + off];
+        __syncthreads();
+    }
+    if (tid < 4) per_walker[(long)w * per_stride + (long)tid * n_dirs + d] = red[tid][0] / (double)n;  // finish!: / N
+}
+// m{x,y,z}_kernel (measurements.jl:112-124; attractive: all zero) and the sum over walkers
+__global__ void corr_reduce_kernel(int n, int nb, int model, int n_walkers, const double *__restrict__ G,
+                                   long stride_unit, int n_dirs, const double *__restrict__ per_walker,
+                                   long per_stride, double *__restrict__ acc)
+{
+    const int total = 4 * n_dirs + 3 * n;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        double s = 0.0;
+        if (e < 4 * n_dirs) {
+            for (int w = 0; w < n_walkers; ++w) s += per_walker[(long)w * per_stride + e];
+        } else if (e >= 4 * n_dirs + 2 * n && model != 0) {  // mz = G_dn[i,i] - G_up[i,i]
+            const int i = e - 4 * n_dirs - 2 * n;
+            for (int w = 0; w < n_walkers; ++w) {
+                const double *G1 = G + (long)(w * nb) * stride_unit;
+                s += G1[stride_unit + i + (long)n * i] - G1[i + (long)n * i];
+            }
+        }
+        acc[e] += s;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) acc[total] += (double)n_walkers;
+}
+hipError_t launch_correlations(int n, int nb, int model, int n_walkers, const double *G, long stride_unit,
+                               const int *dir_ptr, const int *pair_src, const int *pair_trg, int n_dirs,
+                               double *per_walker, double *acc, hipStream_t s)
+{
+    const long per_stride = 4L * n_dirs;
+    hipLaunchKernelGGL(corr_pairs_kernel, dim3(n_dirs, n_walkers), dim3(256), 0, s, n, nb, model, G, stride_unit,
+                       dir_ptr, pair_src, pair_trg, n_dirs, per_walker, per_stride);
+    const int total = 4 * n_dirs + 3 * n;
+    hipLaunchKernelGGL(corr_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, n, nb, model, n_walkers, G,
+                       stride_unit, n_dirs, per_walker, per_stride, acc);
+    return hipGetLastError();
+}
+
 // compress(mc, model, conf) = BitArray(conf .== 1) (HubbardModel.jl:56-59): Julia's BitArray keeps
 // element i (1-based, column-major) in bit (i-1) % 64 of chunk (i-1) / 64.  One wave packs one chunk.
 __global__ void conf_pack_kernel(const int8_t *__restrict__ conf, size_t n_elem, unsigned long long *__restrict__ chunks)

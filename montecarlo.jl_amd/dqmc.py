@@ -322,6 +322,30 @@ class DQMC:
         occ = [acc[2 * B * n * n + b * n:2 * B * n * n + (b + 1) * n] / cnt for b in range(B)]
         return dict(G=G, G2=G2, occupation=occ, count=cnt)
 
+    # ---- equal-time correlations (charge_density_correlation, spin_density_correlation, magnetization)
+    def set_pair_directions(self, iterator):
+        """hand the EachSitePairByDistance table of the lattice to the device"""
+        tab = np.asfortranarray(iterator.dir_of.astype(np.int32))  # [src, trg] -> dir_of[src + n*trg]
+        self._ndirs = iterator.ndirections()
+        self._c(lib().dqmc_set_pair_directions(self._h, tab.ctypes.data_as(C.POINTER(C.c_int32)), self._ndirs))
+
+    def accumulate_correlations(self):
+        self._c(lib().dqmc_accumulate_correlations(self._h))
+
+    def correlations(self):
+        """-> dict of means: CDC, SDCx, SDCy, SDCz per direction; Mx, My, Mz per site; count"""
+        n = C.c_size_t()
+        self._c(lib().dqmc_correlations_size(self._h, C.byref(n)))
+        out = np.zeros(n.value)
+        self._c(lib().dqmc_get_correlations(self._h, dptr(out)))
+        nd, N, cnt = self._ndirs, self.N, out[-1]
+        names = ["CDC", "SDCx", "SDCy", "SDCz"]
+        res = {k: out[i * nd:(i + 1) * nd] / cnt for i, k in enumerate(names)}
+        for i, k in enumerate(["Mx", "My", "Mz"]):
+            res[k] = out[4 * nd + i * N:4 * nd + (i + 1) * N] / cnt
+        res["count"] = cnt
+        return res
+
     # ---- instrumentation
     def timing_enable(self, on=True):
         self._c(lib().dqmc_timing_enable(self._h, int(on)))

@@ -68,3 +68,81 @@ def build_checkerboard(l):
         groups.append((gs, ge - 1))
         gs = ge
     return cb, groups, len(groups)
+
+
+# ---------------------------------------------------------------------------
+# EachSitePairByDistance (src/lattices/lattice_iterators.jl:131-190)
+def _positions(l):
+    """positions(l) (square.jl:72, chain.jl:52): 1-based cartesian coordinates"""
+    if isinstance(l, SquareLattice):
+        return [np.array([i + 1.0, j + 1.0]) for j in range(l.L) for i in range(l.L)]
+    return [np.array([i + 1.0]) for i in range(l.sites)]
+
+
+def _lattice_vectors(l):
+    if isinstance(l, SquareLattice):
+        return [np.array([float(l.L), 0.0]), np.array([0.0, float(l.L)])]
+    return [np.array([float(l.sites)])]
+
+
+def generate_combinations(vs):
+    """lattice_iterators.jl:137-143: all periodic images, in the reference's order"""
+    out = [np.zeros(len(vs[0]))]
+    for v in vs:
+        out = [e - v for e in out] + out + [e + v for e in out]
+    return out
+
+
+def directed_norm(v, eps):
+    """norm + eps * angle(v, e_x) (lattice_iterators.jl:146-155)"""
+    ln = float(np.linalg.norm(v))
+    if len(v) == 2 and ln > eps:
+        angle = float(np.arccos(v[0] / ln))
+        if v[1] < 0:
+            angle = 2 * np.pi - angle
+        return ln + eps * angle
+    return ln
+
+
+class EachSitePairByDistance:
+    """Triplets (direction index, source, target) sorted by distance.  `pairs[d]` lists the 1-based
+    (src, trg) pairs of direction d in the reference's order; `dir_of[src-1, trg-1]` is the 0-based
+    direction index of a pair; `directions[d]` the displacement vector."""
+
+    def __init__(self, lattice, eps=1e-6):
+        pos = _positions(lattice)
+        wrap = generate_combinations(_lattice_vectors(lattice))
+        directions, bonds = [], []
+        for origin in range(len(lattice)):
+            for trg, p in enumerate(pos):
+                d = pos[origin] - p + wrap[0]
+                for v in wrap[1:]:
+                    new_d = pos[origin] - p + v
+                    if directed_norm(new_d, eps) + eps < directed_norm(d, eps):
+                        d = new_d
+                idx = next((k for k, dd in enumerate(directions) if np.linalg.norm(dd - d) <= eps), None)
+                if idx is None:
+                    directions.append(d.copy())
+                    bonds.append([])
+                    idx = len(directions) - 1
+                bonds[idx].append((origin + 1, trg + 1))
+        order = sorted(range(len(directions)), key=lambda k: directed_norm(directions[k], eps))  # stable
+        self.directions = [directions[k] for k in order]
+        self.pairs = [bonds[k] for k in order]
+        self.N = len(lattice) ** 2
+        n = len(lattice)
+        self.dir_of = np.zeros((n, n), dtype=np.int32)
+        for d, prs in enumerate(self.pairs):
+            for s, t in prs:
+                self.dir_of[s - 1, t - 1] = d
+
+    def __len__(self):
+        return self.N
+
+    def ndirections(self):
+        return len(self.pairs)
+
+    def __iter__(self):
+        for d, prs in enumerate(self.pairs):
+            for s, t in prs:
+                yield d + 1, s, t

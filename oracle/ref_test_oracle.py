@@ -128,3 +128,115 @@ def ed_hubbard_greens(neighs, n_sites, U, t, mu, beta):
         for b_ in range(nm):
             G[a_, b_] = np.trace(rho @ c[a_] @ cd[b_]) / Z
     return G
+
+
+# --------------------------------------------------------------------------
+# Equal-time measurement kernels in their generic 2N x 2N form
+# (src/flavors/DQMC/measurements/measurements.jl:51-190) and the pair iterator
+# (src/lattices/lattice_iterators.jl:137-190), restated independently of the product.
+def full_greens(blocks):
+    """greens(mc, model): the 2N x 2N matrix (attractive: blockdiag(G, G), Attractive.jl:169-172)"""
+    n = blocks[0].shape[0]
+    G = np.zeros((2 * n, 2 * n))
+    G[:n, :n] = blocks[0]
+    G[n:, n:] = blocks[1] if len(blocks) == 2 else blocks[0]
+    return G
+
+
+def cdc_kernel(G, N, i, j):
+    d = 1.0 if i == j else 0.0
+    return ((1 - G[i, i]) * (1 - G[j, j]) + (d - G[j, i]) * G[i, j]
+            + (1 - G[i, i]) * (1 - G[j + N, j + N]) - G[j + N, i] * G[i, j + N]
+            + (1 - G[i + N, i + N]) * (1 - G[j, j]) - G[j, i + N] * G[i + N, j]
+            + (1 - G[i + N, i + N]) * (1 - G[j + N, j + N]) + (d - G[j + N, i + N]) * G[i + N, j + N])
+
+
+def sdc_x_kernel(G, N, i, j):
+    d = 1.0 if i == j else 0.0
+    return (G[i + N, i] * G[j + N, j] - G[j + N, i] * G[i + N, j]
+            + G[i + N, i] * G[j, j + N] + (d - G[j, i]) * G[i + N, j + N]
+            + G[i, i + N] * G[j + N, j] + (d - G[j + N, i + N]) * G[i, j]
+            + G[i, i + N] * G[j, j + N] - G[j, i + N] * G[i, j + N])
+
+
+def sdc_y_kernel(G, N, i, j):
+    d = 1.0 if i == j else 0.0
+    return (-G[i + N, i] * G[j + N, j] + G[j + N, i] * G[i + N, j]
+            + G[i + N, i] * G[j, j + N] + (d - G[j, i]) * G[i + N, j + N]
+            + G[i, i + N] * G[j + N, j] + (d - G[j + N, i + N]) * G[i, j]
+            - G[i, i + N] * G[j, j + N] + G[j, i + N] * G[i, j + N])
+
+
+def sdc_z_kernel(G, N, i, j):
+    d = 1.0 if i == j else 0.0
+    return ((1 - G[i, i]) * (1 - G[j, j]) + (d - G[j, i]) * G[i, j]
+            - (1 - G[i, i]) * (1 - G[j + N, j + N]) + G[j + N, i] * G[i, j + N]
+            - (1 - G[i + N, i + N]) * (1 - G[j, j]) + G[j, i + N] * G[i + N, j]
+            + (1 - G[i + N, i + N]) * (1 - G[j + N, j + N]) + (d - G[j + N, i + N]) * G[i + N, j + N])
+
+
+def square_pair_directions(L, eps=1e-6):
+    """EachSitePairByDistance(SquareLattice(L)): list of displacement vectors (sorted) and the
+    0-based direction index of every (src, trg) pair, src/trg 0-based column-major sites"""
+    pos = [np.array([i + 1.0, j + 1.0]) for j in range(L) for i in range(L)]
+    wrap = [np.zeros(2)]
+    for v in (np.array([float(L), 0.0]), np.array([0.0, float(L)])):
+        wrap = [e - v for e in wrap] + wrap + [e + v for e in wrap]
+
+    def dnorm(v):
+        ln = np.hypot(v[0], v[1])
+        if ln > eps:
+            a = np.arccos(v[0] / ln)
+            if v[1] < 0:
+                a = 2 * np.pi - a
+            return ln + eps * a
+        return ln
+
+    dirs, first = [], {}
+    table = np.zeros((L * L, L * L), dtype=np.int64)
+    for o in range(L * L):
+        for t in range(L * L):
+            d = pos[o] - pos[t] + wrap[0]
+            for v in wrap[1:]:
+                nd = pos[o] - pos[t] + v
+                if dnorm(nd) + eps < dnorm(d):
+                    d = nd
+            key = (int(round(d[0])), int(round(d[1])))
+            if key not in first:
+                first[key] = len(dirs)
+                dirs.append(d.copy())
+            table[o, t] = first[key]
+    order = sorted(range(len(dirs)), key=lambda k: dnorm(dirs[k]))
+    rank = np.empty(len(dirs), dtype=np.int64)
+    rank[order] = np.arange(len(dirs))
+    return [dirs[k] for k in order], rank[table]
+
+
+def equal_time_correlations(blocks, L, attractive):
+    """what apply!(EachSitePairByDistance, ...) + finish! push for CDC, SDCx/y/z (generic.jl:325-330,
+    283-286) and m{x,y,z}_kernel per site, from the block Green's functions of one configuration"""
+    N = L * L
+    G = full_greens(blocks)
+    dirs, table = square_pair_directions(L)
+    nd = len(dirs)
+    out = {k: np.zeros(nd) for k in ("CDC", "SDCx", "SDCy", "SDCz")}
+    for i in range(N):
+        for j in range(N):
+            d = table[i, j]
+            if attractive:  # HubbardModelAttractive.jl:222-236 overrides
+                dij = 1.0 if i == j else 0.0
+                t = 2 * (dij - G[j, i]) * G[i, j]
+                out["CDC"][d] += 4 * (1 - G[i, i]) * (1 - G[j, j]) + t
+                out["SDCx"][d] += t; out["SDCy"][d] += t; out["SDCz"][d] += t
+            else:
+                out["CDC"][d] += cdc_kernel(G, N, i, j)
+                out["SDCx"][d] += sdc_x_kernel(G, N, i, j)
+                out["SDCy"][d] += sdc_y_kernel(G, N, i, j)
+                out["SDCz"][d] += sdc_z_kernel(G, N, i, j)
+    for k in out:
+        out[k] /= N
+    z = np.zeros(N)
+    out["Mx"] = z.copy() if attractive else np.array([-G[i + N, i] - G[i, i + N] for i in range(N)])
+    out["My"] = z.copy() if attractive else np.array([G[i + N, i] - G[i, i + N] for i in range(N)])
+    out["Mz"] = z.copy() if attractive else np.array([G[i + N, i + N] - G[i, i] for i in range(N)])
+    return out

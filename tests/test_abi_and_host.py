@@ -119,3 +119,24 @@ def test_compress_layout_host(mc_amd):
     assert np.array_equal(mc_amd.decompress(cc), c)
     r = mc_amd.ConfigRecorder(rate=3)
     assert len(r) == 0 and len(mc_amd.Discarder()) == 0
+
+
+def test_pair_iterator_contracts(mc_amd, R):
+    """test/lattices.jl:52-58,112-140: directions sorted by norm; every pair's minimal-image
+    displacement equals the direction it is filed under; N^2 pairs.  The product's table equals the
+    independent restatement in oracle/ref_test_oracle.py."""
+    for L in (3, 4):
+        l = mc_amd.SquareLattice(L)
+        it = mc_amd.EachSitePairByDistance(l)
+        norms = [np.linalg.norm(d) for d in it.directions]
+        assert all(norms[i - 1] < norms[i] + 1e-5 for i in range(1, len(norms)))
+        trip = list(it)
+        assert len(trip) == len(it) == (L * L) ** 2 and it.ndirections() == L * L
+        dirs, table = R.square_pair_directions(L)
+        assert np.array_equal(table, it.dir_of)
+        for d, s, t in trip[:: 7]:
+            i1, j1 = (s - 1) % L, (s - 1) // L
+            i2, j2 = (t - 1) % L, (t - 1) // L
+            dv = it.directions[d - 1]
+            assert (i1 - i2 - dv[0]) % L == 0 and (j1 - j2 - dv[1]) % L == 0
+    assert list(mc_amd.EachSitePairByDistance(mc_amd.SquareLattice(4)).directions[0]) == [0.0, 0.0]

@@ -1,0 +1,39 @@
+"""equal-time correlation measurements on the device against the generic 2N x 2N
+kernel formulas restated in oracle/ref_test_oracle.py (measurements.jl:51-190)."""
+import numpy as np
+import pytest
+
+from conftest import relerr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("kind", ["attractive", "repulsive"])
+def test_correlations_match_reference_formulas(gpu, O, R, kind):
+    L = 4
+    model = (gpu.HubbardModelAttractive if kind == "attractive" else gpu.HubbardModelRepulsive)(L, 2)
+    mc = gpu.DQMC(model, beta=1.0, n_walkers=3, seed=31)
+    it = gpu.EachSitePairByDistance(model.l)
+    mc.set_pair_directions(it)
+    mc.prepare()
+    mc.update_until_measure()
+    mc.reset_accumulators()
+    mc.accumulate_correlations()
+    mc.update_until_measure()
+    mc.accumulate_correlations()
+    res = mc.correlations()
+    assert res["count"] == 6
+    # reference: same trajectories with the oracle, formulas in their generic form
+    ref = None
+    for w in range(3):
+        o = O.OracleDQMC(L, kind, beta=1.0)
+        rng = np.random.Generator(np.random.Philox(key=mc.seeds[w]))
+        o.set_conf(gpu.rand_conf(rng, 16, 10)); o.seed(mc.seeds[w])
+        o.prepare()
+        for _ in range(2):
+            o.update_until_measure()
+            c = R.equal_time_correlations(o.greens(), L, kind == "attractive")
+            ref = c if ref is None else {k: ref[k] + c[k] for k in c}
+    for k in ("CDC", "SDCx", "SDCy", "SDCz", "Mx", "My", "Mz"):
+        assert np.abs(res[k] - ref[k] / 6).max() < 1e-10, k
+    mc.close()

@@ -231,3 +231,24 @@ def test_ising_plumbing(O):
     assert abs(M - 25.47) < 3 * 0.82 + 0.3
     assert abs(E - (-59.10)) < 3 * 0.88 + 0.3
     assert 0 < r.accepted < r.proposed == 64 * 41000
+
+
+def test_correlation_goldens(O, R):
+    """test/integration_tests.jl:59-75: charge / spin density correlations of the attractive 4x4 run,
+    16 directions in EachSitePairByDistance order (pins kernel formulas + direction ordering
+    statistically: on-site, 4 nearest neighbours, ...)"""
+    g = gold("integration_attractive_4x4.json")
+    mc = O.OracleDQMC(4, "attractive", beta=1.0)
+    mc.set_conf(O.random_conf(123, 16, 10)); mc.seed(123)
+    mc.prepare(); mc.sweeps(50)
+    acc = None
+    n = 400
+    for _ in range(n):
+        mc.update_until_measure()
+        c = R.equal_time_correlations(mc.greens(), 4, True)
+        acc = c if acc is None else {k: acc[k] + c[k] for k in c}
+    cdc, sdc = acc["CDC"] / n, acc["SDCx"] / n
+    assert np.abs(cdc - np.array(g["CDC_mean"])).max() < g["atol"] + 0.02
+    assert np.abs(sdc - np.array(g["SDCx_mean"])).max() < g["atol"]
+    # structure: on-site first, then the four symmetry-equivalent nearest neighbours
+    assert cdc[0] > 1.4 and np.ptp(cdc[1:5]) < 0.02

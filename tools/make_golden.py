@@ -42,9 +42,15 @@ def main():
     g_att = [float(x) for x in g_att.replace("\n", " ").split(",")]
     g_rep = re.search(r"# Greens\s*@test \[(.*?)\]\s*≈ measured\[:G\] \|> mean", rep, re.S).group(1)
     g_rep = julia_matrix(g_rep.replace("\n", " "))
-    json.dump({"source": "test/integration_tests.jl:29-49 (attractive 4x4, beta=1, 10+1000 sweeps, "
+    def vec(block, pat):
+        t = re.search(pat, block, re.S).group(1)
+        return [float(x) for x in t.replace("\n", " ").split(",")]
+    cdc_att = vec(att, r"# Charge Density Correlation\s*@test \[(.*?)\]\[:\] ≈ mean\(measured\[:CDC\]\)")
+    sdcx_att = vec(att, r"# Spin density correlations \(x, y, z\)\s*@test \[(.*?)\]\[:\] ≈ mean\(measured\[:SDCx\]\)")
+    json.dump({"source": "test/integration_tests.jl:29-75 (attractive 4x4, beta=1, 10+1000 sweeps, "
                          "measure_rate 10; atol = 4*dtau^2 = 0.04)", "L": 4, "beta": 1.0, "atol": 0.04,
-               "G_mean_colmajor": g_att}, open(os.path.join(OUT, "integration_attractive_4x4.json"), "w"))
+               "G_mean_colmajor": g_att, "CDC_mean": cdc_att, "SDCx_mean": sdcx_att},
+              open(os.path.join(OUT, "integration_attractive_4x4.json"), "w"))
     json.dump({"source": "test/integration_tests.jl:95-118 (repulsive 2x2, beta=1, 10+1000 sweeps; "
                          "atol = 2*dtau^2 = 0.02)", "L": 2, "beta": 1.0, "atol": 0.02, "G_mean": g_rep},
               open(os.path.join(OUT, "integration_repulsive_2x2.json"), "w"))
