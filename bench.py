@@ -81,12 +81,17 @@ def main():
     ap.add_argument("--cpu-sweeps", type=int, default=2)
     args = ap.parse_args()
 
+    # stdout must carry exactly ONE JSON line: native libraries (the RCCL banner, HIP warnings) write
+    # to fd 1 as well, so fd 1 is pointed at stderr for the run and the JSON goes to the saved fd
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("BENCH_FORCE_DIST"):  # the env var exercises the RCCL path on one rank
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -181,7 +186,8 @@ def main():
                                          "workload, %.1f s; restatement of MonteCarlo.jl's algorithm, not the "
                                          "Julia package" % (cores, args.cpu_sweeps, secs)}
     if rank == 0:
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     mc.close()
     if dist is not None:
         dist.destroy_process_group()
