@@ -59,6 +59,7 @@ struct dqmc_handle {
     double fam_ms[DQMC_K_COUNT] = {0};
     long long fam_n[DQMC_K_COUNT] = {0};
     std::vector<void *> allocs;
+    QrCoopWorkspace qr_ws;
 };
 
 // ---------------------------------------------------------------------------
@@ -207,6 +208,28 @@ static int set_ones(dqmc_handle *h, double *d)
     return 0;
 }
 
+static int alloc_qr_workspace(dqmc_handle *h)
+{
+    if (h->n > 256) return 0;
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, h->p.device_id));
+    const size_t slots = (size_t)((h->units + 7) / 8) * 8 * 2 * 8;
+    CHK(dalloc(h, &h->qr_ws.mailbox, slots * QR_COOP_SLOT));
+    CHK(dalloc(h, &h->qr_ws.flags, slots));
+    CHK(dalloc(h, &h->qr_ws.errflag, (size_t)1));
+    h->qr_ws.max_blocks = prop.multiProcessorCount;  // one workgroup per CU: co-residency beyond doubt
+    h->qr_ws.epoch = 0;
+    return 0;
+}
+static int check_qr_workspace(dqmc_handle *h)
+{
+    if (!h->qr_ws.errflag) return 0;
+    int e = 0;
+    HIPCHK(hipMemcpy(&e, h->qr_ws.errflag, sizeof(int), hipMemcpyDeviceToHost));
+    if (e) return fail(h, DQMC_ERR_HIP, "cooperative QR: hand-off timed out");
+    return 0;
+}
+
 // ---- UDT (udt_AVX_pivot!, src/linalg/UDT.jl:192-306) ---------------------------
 // A is factored in place.  Q is formed in compact-WY form with GEMMs instead of the
 // reference's reflector-by-reflector back accumulation (UDT.jl:250-266):
@@ -216,7 +239,7 @@ static int udt(dqmc_handle *h, double *A, double *Uout, double *Dout, double *To
     const int n = h->n;
     {
         Timed t(h, DQMC_K_QR);
-        HIPCHK(launch_qr_pivot(n, h->units, A, h->nn, h->tau, h->pivot, h->stream));
+        HIPCHK(launch_qr_pivot(n, h->units, A, h->nn, h->tau, h->pivot, &h->qr_ws, h->stream));
     }
     {
         Timed t(h, DQMC_K_MISC);
@@ -557,6 +580,7 @@ int dqmc_create(const dqmc_params *p, dqmc_handle **out)
     for (auto m : mats) CCHK(dalloc(h, m, un));
     CCHK(dalloc(h, &h->Dl, uv)); CCHK(dalloc(h, &h->Dr, uv)); CCHK(dalloc(h, &h->tau, uv));
     CCHK(dalloc(h, &h->pivot, uv));
+    CCHK(alloc_qr_workspace(h));
     CCHK(dalloc(h, &h->sU, (size_t)h->units * h->n * h->kd));
     CCHK(dalloc(h, &h->sVT, (size_t)h->units * h->n * h->kd));
     CCHK(dalloc(h, &h->rng, (size_t)h->W));
@@ -672,6 +696,7 @@ int dqmc_synchronize(dqmc_handle *h)
     ENTER(h);
     HIPCHK(hipStreamSynchronize(h->stream));
     CHK(timing_drain(h));
+    CHK(check_qr_workspace(h));
     return check_rng(h);
 }
 int dqmc_build_stack(dqmc_handle *h)
@@ -1095,6 +1120,7 @@ static int scratch_udt_bufs(dqmc_handle *h)
     const size_t un = (size_t)h->units * h->nn, uv = (size_t)h->units * h->n;
     CHK(dalloc(h, &h->qrV, un)); CHK(dalloc(h, &h->qrW, un)); CHK(dalloc(h, &h->qrS, un));
     CHK(dalloc(h, &h->tau, uv)); CHK(dalloc(h, &h->pivot, uv));
+    CHK(alloc_qr_workspace(h));
     return 0;
 }
 

@@ -52,8 +52,19 @@ hipError_t launch_gemm(const GemmArgs &g, hipStream_t s);
 // src/linalg/UDT.jl:212-246).  On exit A holds R on/above the diagonal and the
 // Householder vectors below it (unit diagonal implied), tau[n], pivot[n] (0-based:
 // column j of the factored matrix is original column pivot[j]).
+// Workspace of the cooperative (8 workgroups per matrix) QR: mailbox of n_units x 2 x 8 slots of
+// QR_COOP_SLOT doubles, n_units x 2 x 8 tags, an error flag (bounded spins), a launch counter.
+constexpr int QR_COOP_SLOT = 264;
+struct QrCoopWorkspace {
+    double *mailbox = nullptr;
+    unsigned long long *flags = nullptr;
+    int *errflag = nullptr;
+    unsigned long long epoch = 0;
+    int max_blocks = 0;   // launch the cooperative kernel only if its grid fits (co-residency)
+};
+// ws may be null: single-workgroup kernels only
 hipError_t launch_qr_pivot(int n, int n_units, double *A, long strideA, double *tau, int *pivot,
-                           hipStream_t s);
+                           QrCoopWorkspace *ws, hipStream_t s);
 
 // After launch_qr_pivot: D = |diag R| (UDT.jl:268-272); V = unit-lower Householder
 // vectors (n x n, explicit zeros/ones); T = D^-1 R:

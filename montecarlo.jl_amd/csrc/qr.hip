@@ -467,9 +467,224 @@ __global__ __launch_bounds__(QT_THREADS) void qr_tile256_kernel(int n, int nstep
     if (tid < n) piv[tid] = pv[tid];
 }
 
-hipError_t launch_qr_pivot(int n, int n_units, double *A, long strideA, double *tau, int *pivot, hipStream_t s)
+// ---------------------------------------------------------------------------
+// Cooperative variant for n <= 256: EIGHT workgroups factor one matrix, so that the 32 matrices of
+// the benchmark batch occupy all 256 CUs instead of 32, and every workgroup's share (32 columns)
+// lives in registers: 256 threads, thread (wave w, lane l): row group rg = l & 7, column group
+// cg = l >> 3 holds rows rg + 8k (k = 0..31) of ORIGINAL column c = part + 8 (8 w + cg).
+// Pivoting is logical (no column ever moves between workgroups): every workgroup keeps the same
+// replicated position tables pos[column], colat[position], so the reference's tie-break (first
+// maximum in position order, UDT.jl:151-168) and its swap bookkeeping (UDT.jl:219-231) are kept.
+//
+// One hand-off per step through a global mailbox (MI355X_MICROARCH.md, "Valid forms"): each
+// workgroup publishes {norm, position, column id} and the raw column of its best live column
+// with agent-scope relaxed (sc1, write-through) stores, drains them (s_waitcnt vmcnt(0)), passes a
+// workgroup barrier and only then stores its tag; consumers poll the 8 tags with sc1 loads from 8
+// lanes, then read headers and the winning column with sc1 loads.  Tags are epoch*1024 + step + 1
+// (no reset between launches), mailboxes are double buffered by step parity (the skew between
+// workgroups is at most one step, because a step cannot finish without everybody's tag).  Every
+// spin is bounded; a timeout raises a flag that the host reports.
+constexpr int QC_PARTS = 8;
+constexpr int QC_MB = 264;          // doubles per mailbox slot: 256 column entries + 8 header words
+constexpr unsigned QC_SPIN_LIMIT = 4000000u;
+
+__device__ __forceinline__ void qc_store(double *p, double v)
+{
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double qc_load(const double *p)
+{
+    return __longlong_as_double((long long)__hip_atomic_load(
+        reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+__global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double *__restrict__ Aall, long strideA,
+                                                     double *__restrict__ tauall, int *__restrict__ pivall,
+                                                     double *mailbox, unsigned long long *flags,
+                                                     unsigned long long epoch, int *errflag)
+{
+    __shared__ __attribute__((aligned(16))) double colbuf[256];   // my best column / the winning column
+    __shared__ __attribute__((aligned(16))) double vperm[8 * QT_VS];
+    __shared__ double dummy[256];
+    __shared__ double hdr_norm[QC_PARTS];
+    __shared__ int hdr_pos[QC_PARTS], hdr_col[QC_PARTS];
+    __shared__ double wc_norm[4];
+    __shared__ int wc_pos[4], wc_col[4];
+    __shared__ int pos[256], colat[256];
+    __shared__ int s_abort;
+
+    const int bid = blockIdx.x, xcd = bid & 7, seq = bid >> 3;
+    const int unit = (seq / QC_PARTS) * 8 + xcd, part = seq % QC_PARTS;
+    if (unit >= n_units) return;  // all parts of a missing unit leave together
+    double *__restrict__ A = Aall + (long)unit * strideA;
+    double *__restrict__ tau = tauall + (long)unit * n;
+    int *__restrict__ piv = pivall + (long)unit * n;
+    double *mb_unit = mailbox + (long)unit * 2 * QC_PARTS * QC_MB;
+    unsigned long long *fl_unit = flags + (long)unit * 2 * QC_PARTS;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, rg = lane & 7, cg = lane >> 3;
+    const int c = part + 8 * (8 * w + cg);  // my original column
+    double x[32];
+    double nrm = 0.0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        const int r = rg + 8 * k;
+        const double a = (r < n && c < n) ? A[r + (long)n * c] : 0.0;
+        x[k] = a;
+        nrm += a * a;
+    }
+    nrm = sum8(nrm);  // full squared norm of column c, in all 8 lanes of the column
+    pos[tid] = tid;
+    colat[tid] = tid;
+    if (tid == 0) s_abort = 0;
+    __syncthreads();
+
+    for (int j = 0; j < n; ++j) {
+        const int par = j & 1;
+        const unsigned long long tag = epoch * 1024ull + (unsigned long long)j + 1ull;
+        // ---- my workgroup's best live column: larger norm first, then smaller position
+        {
+            double bn = -1.0;
+            int bp = 0x7fffffff, bc = -1;
+            if (c < n && pos[c] >= j) { bn = nrm; bp = pos[c]; bc = c; }
+#pragma unroll
+            for (int off = 8; off < 64; off <<= 1) {
+                const double on = __shfl_xor(bn, off, 64);
+                const int op = __shfl_xor(bp, off, 64), oc = __shfl_xor(bc, off, 64);
+                if (on > bn || (on == bn && op < bp)) { bn = on; bp = op; bc = oc; }
+            }
+            if (lane == 0) { wc_norm[w] = bn; wc_pos[w] = bp; wc_col[w] = bc; }
+        }
+        __syncthreads();
+        double lbn = wc_norm[0];
+        int lbp = wc_pos[0], lbc = wc_col[0];
+#pragma unroll
+        for (int q = 1; q < 4; ++q)
+            if (wc_norm[q] > lbn || (wc_norm[q] == lbn && wc_pos[q] < lbp)) { lbn = wc_norm[q]; lbp = wc_pos[q]; lbc = wc_col[q]; }
+        // ---- its owner lanes put the column into LDS (wave-uniform branch, dummy sink for other lanes)
+        if (lbc >= 0 && w == ((lbc >> 3) >> 3)) {
+            double *dst = (cg == ((lbc >> 3) & 7)) ? colbuf : dummy;
+#pragma unroll
+            for (int k = 0; k < 32; ++k) dst[rg + 8 * k] = x[k];
+        }
+        __syncthreads();
+        // ---- publish: raw column + header, drained, then the tag
+        {
+            double *mb = mb_unit + (long)(par * QC_PARTS + part) * QC_MB;
+            qc_store(mb + tid, lbc >= 0 ? colbuf[tid] : 0.0);
+            if (tid == 0) {
+                qc_store(mb + 256, lbn);
+                qc_store(mb + 257, (double)lbp);
+                qc_store(mb + 258, (double)lbc);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0)
+                __hip_atomic_store(fl_unit + par * QC_PARTS + part, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // ---- collect: 8 lanes poll the 8 tags and fetch the headers behind them
+        if (tid < QC_PARTS) {
+            unsigned spins = 0;
+            while (__hip_atomic_load(fl_unit + par * QC_PARTS + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tag) {
+                if (++spins > QC_SPIN_LIMIT) { s_abort = 1; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            const double *mb = mb_unit + (long)(par * QC_PARTS + tid) * QC_MB;
+            hdr_norm[tid] = qc_load(mb + 256);
+            hdr_pos[tid] = (int)qc_load(mb + 257);
+            hdr_col[tid] = (int)qc_load(mb + 258);
+        }
+        __syncthreads();
+        if (s_abort) break;
+        double maxval = hdr_norm[0];
+        int jm = hdr_pos[0], cm = hdr_col[0], wpart = 0;
+#pragma unroll
+        for (int q = 1; q < QC_PARTS; ++q)
+            if (hdr_norm[q] > maxval || (hdr_norm[q] == maxval && hdr_pos[q] < jm)) {
+                maxval = hdr_norm[q]; jm = hdr_pos[q]; cm = hdr_col[q]; wpart = q;
+            }
+        if (cm < 0) { cm = colat[j]; jm = j; maxval = 0.0; wpart = cm & 7; }  // nothing live: cannot happen for j < n
+        // ---- the winning column (sc1 loads), reflector (UDT.jl:133-148), output column j
+        const double cv = qc_load(mb_unit + (long)(par * QC_PARTS + wpart) * QC_MB + tid);
+        colbuf[tid] = cv;  // my own copy was the same data if I am the winner
+        __syncthreads();
+        const double xi1 = colbuf[j];
+        double tj = 0.0, nu = 0.0, xi = 1.0;
+        if (maxval != 0.0) {
+            nu = copysign(sqrt(maxval), xi1);
+            xi = xi1 + nu;
+            tj = xi / nu;
+        }
+        {
+            const int r = tid;
+            double outv = cv, vr = (r == j) ? 1.0 : 0.0;
+            if (maxval != 0.0) {
+                if (r == j) outv = -nu;
+                else if (r > j) { outv = cv / xi; vr = outv; }
+            }
+            if (r >= n) vr = 0.0;
+            vperm[(r & 7) * QT_VS + (r >> 3)] = vr;
+            if (part == wpart && r < n) A[r + (long)n * j] = outv;  // the owner writes the finished column
+        }
+        if (tid == 0) {
+            if (part == wpart) tau[j] = tj;
+            const int cj = colat[j];  // swap positions j <-> jm (UDT.jl:219-231), replicated everywhere
+            pos[cm] = j;
+            colat[j] = cm;
+            if (jm != j) { pos[cj] = jm; colat[jm] = cj; }
+        }
+        __syncthreads();
+        // ---- apply H_j to my column if it is still live (reflectorApply!, UDT.jl:32-50); fresh norm
+        if (c < n && pos[c] > j) {
+            const double *vq = vperm + rg * QT_VS;
+            double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+            for (int k = 0; k < 32; k += 2) {
+                const double2 v2 = *reinterpret_cast<const double2 *>(vq + k);
+                d0 += v2.x * x[k];
+                d1 += v2.y * x[k + 1];
+            }
+            const double wv = sum8(d0 + d1) * tj;
+            double n0 = 0.0, n1 = 0.0;
+#pragma unroll
+            for (int k = 0; k < 32; k += 2) {
+                const double2 v2 = *reinterpret_cast<const double2 *>(vq + k);
+                const double y0 = x[k] - v2.x * wv, y1 = x[k + 1] - v2.y * wv;
+                x[k] = y0;
+                x[k + 1] = y1;
+                n0 += (rg + 8 * k > j ? 1.0 : 0.0) * (y0 * y0);
+                n1 += (rg + 8 * (k + 1) > j ? 1.0 : 0.0) * (y1 * y1);
+            }
+            nrm = sum8(n0 + n1);
+        }
+        // (pos/colat are rewritten by thread 0 only after the barriers of the next step)
+    }
+    if (s_abort) {
+        if (tid == 0) atomicExch(errflag, 1);
+        return;
+    }
+    __syncthreads();
+    if (part == 0 && tid < n) piv[tid] = colat[tid];
+}
+
+hipError_t launch_qr_pivot(int n, int n_units, double *A, long strideA, double *tau, int *pivot, QrCoopWorkspace *ws,
+                           hipStream_t s)
 {
     if (n > 1024) return hipErrorInvalidValue;
+    static const bool no_coop = getenv("DQMC_QR_NOCOOP") != nullptr;
+    // cooperative kernel: all 8 workgroups of every unit must be co-resident (they wait for each
+    // other), which the grid size guarantees only while it stays well below the chip's capacity
+    if (ws && ws->mailbox && n <= 256 && !no_coop) {
+        const int groups = (n_units + 7) / 8;
+        const int blocks = groups * 8 * QC_PARTS;
+        if (blocks <= ws->max_blocks) {
+            ws->epoch += 1;
+            hipLaunchKernelGGL(qr_coop_kernel, dim3(blocks), dim3(256), 0, s, n, n_units, A, strideA, tau, pivot,
+                               ws->mailbox, ws->flags, ws->epoch, ws->errflag);
+            return hipGetLastError();
+        }
+    }
     static const bool no_tile = getenv("DQMC_QR_STREAM") != nullptr;
     if (n > 128 && n <= 256 && !no_tile) {
         const size_t lds_t = (64 * QT_LSTRIDE + 3 * 256 + 8 * QT_VS + 8 * 256) * sizeof(double) + 256 * sizeof(int);
