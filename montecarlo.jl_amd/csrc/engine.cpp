@@ -217,7 +217,8 @@ static int alloc_qr_workspace(dqmc_handle *h)
     CHK(dalloc(h, &h->qr_ws.mailbox, slots * QR_COOP_SLOT));
     CHK(dalloc(h, &h->qr_ws.flags, slots));
     CHK(dalloc(h, &h->qr_ws.errflag, (size_t)1));
-    h->qr_ws.max_blocks = prop.multiProcessorCount;  // one workgroup per CU: co-residency beyond doubt
+    // co-residency: the kernel's 200 VGPRs admit 2 workgroups of 256 threads per CU
+    h->qr_ws.max_blocks = prop.multiProcessorCount * 2;
     h->qr_ws.epoch = 0;
     return 0;
 }
