@@ -844,26 +844,52 @@ __global__ __launch_bounds__(128) void trsm_mfma_kernel(int n, const double *__r
         Xs[j * TM_XS + r] = row < n ? A[row + (long)n * pj] : 0.0;
     }
     const int nblk = (n + 15) >> 4;
+    // the T panel of block J+1 is requested from global memory (L2) while block J computes:
+    // thread (c = tid >> 3) holds k = (tid & 7) + 8 i of column j0 + c in registers until the LDS panel is free
+    double pre[32], pre_rd = 0.0;
+    auto fetch_panel = [&](int J) {
+        const int j0 = J << 4, c = tid >> 3, col = j0 + c;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const int k = (tid & 7) + 8 * i;
+            pre[i] = (J < nblk && k < j0 + 16 && col < n && k <= col) ? T[k + (long)n * col] : 0.0;
+        }
+        if (tid < 16) {
+            const int cc = j0 + tid;
+            pre_rd = (J < nblk && cc < n) ? (dmul ? dmul[cc] : 1.0 / T[cc + (long)n * cc]) : 0.0;
+        }
+    };
+    fetch_panel(0);
     for (int J = 0; J < nblk; ++J) {
         const int j0 = J << 4;
         __syncthreads();  // previous block's panel no longer read; first pass: Xs complete
-        {   // stage the panel: thread (c = tid >> 3) walks k = (tid & 7) + 8 i over 0 .. j0 + c
-            const int c = tid >> 3, col = j0 + c;
-            for (int k = tid & 7; k < j0 + 16; k += 8)
-                Tp[c * TM_TS + k] = (col < n && k <= col) ? T[k + (long)n * col] : 0.0;
-            if (tid < 16) {
-                const int cc = j0 + tid;
-                rd[tid] = cc < n ? (dmul ? dmul[cc] : 1.0 / T[cc + (long)n * cc]) : 0.0;
+        {
+            const int c = tid >> 3;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const int k = (tid & 7) + 8 * i;
+                if (k < j0 + 16) Tp[c * TM_TS + k] = pre[i];
             }
+            if (tid < 16) rd[tid] = pre_rd;
         }
         __syncthreads();
-        // acc[i = lq + 4 r][c = li] = sum_{k < j0} X[16 w + i, k] T[k, j0 + c]
-        d4_t acc = {0.0, 0.0, 0.0, 0.0};
-        for (int kk = 0; kk < j0; kk += 4) {
+        fetch_panel(J + 1);
+        // acc[i = lq + 4 r][c = li] = sum_{k < j0} X[16 w + i, k] T[k, j0 + c]; two independent
+        // accumulators (a dependent MFMA chain would expose the 64+ cycle MFMA latency per k-step)
+        d4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+        int kk = 0;
+        for (; kk + 8 <= j0; kk += 8) {
+            const double a0 = Xs[(kk + lq) * TM_XS + 16 * w + li], b0 = Tp[li * TM_TS + kk + lq];
+            const double a1 = Xs[(kk + 4 + lq) * TM_XS + 16 * w + li], b1 = Tp[li * TM_TS + kk + 4 + lq];
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc1, 0, 0, 0);
+        }
+        for (; kk < j0; kk += 4) {
             const double a = Xs[(kk + lq) * TM_XS + 16 * w + li];
             const double b = Tp[li * TM_TS + kk + lq];
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc0, 0, 0, 0);
         }
+        const d4_t acc = acc0 + acc1;
 #pragma unroll
         for (int r = 0; r < 4; ++r) Xs[(j0 + li) * TM_XS + 16 * w + lq + 4 * r] -= acc[r];
         // substitution inside the block: lane = row (the wave's own 16 rows; LDS ops of one wave are ordered)
@@ -872,10 +898,14 @@ __global__ __launch_bounds__(128) void trsm_mfma_kernel(int n, const double *__r
             const int row = 16 * w + lane;
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
-                double x = Xs[(j0 + c) * TM_XS + row];
+                double x = Xs[(j0 + c) * TM_XS + row], x2 = 0.0;  // two partial sums: shorter FMA chains
 #pragma unroll
-                for (int c2 = 0; c2 < c; ++c2) x -= xs[c2] * Tp[c * TM_TS + j0 + c2];
-                x *= rd[c];
+                for (int c2 = 0; c2 + 1 < c; c2 += 2) {
+                    x -= xs[c2] * Tp[c * TM_TS + j0 + c2];
+                    x2 -= xs[c2 + 1] * Tp[c * TM_TS + j0 + c2 + 1];
+                }
+                if (c & 1) x -= xs[c - 1] * Tp[c * TM_TS + j0 + c - 1];
+                x = (x + x2) * rd[c];
                 xs[c] = x;
                 Xs[(j0 + c) * TM_XS + row] = x;
             }
