@@ -607,12 +607,13 @@ __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double
         if (cm < 0) { cm = colat[j]; jm = j; maxval = 0.0; wpart = cm & 7; }  // nothing live: cannot happen for j < n
         // ---- the winning column (sc1 loads), reflector (UDT.jl:133-148), output column j
         const double cv = qc_load(mb_unit + (long)(par * QC_PARTS + wpart) * QC_MB + tid);
-        colbuf[tid] = cv;  // my own copy was the same data if I am the winner
+        const double rootn = sqrt(maxval);  // overlaps the column load
+        colbuf[tid] = cv;
         __syncthreads();
         const double xi1 = colbuf[j];
         double tj = 0.0, nu = 0.0, xi = 1.0;
         if (maxval != 0.0) {
-            nu = copysign(sqrt(maxval), xi1);
+            nu = copysign(rootn, xi1);
             xi = xi1 + nu;
             tj = xi / nu;
         }
