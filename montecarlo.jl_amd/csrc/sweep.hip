@@ -44,17 +44,22 @@ __device__ __forceinline__ void magstats_push(DevMagStats &s, double value)
     s.count += 1;
 }
 
-constexpr int SW_GROUP = 8;  // sites per unrolled group (static register indices inside)
+constexpr int SW_GROUP = 8;   // sites per group (static register indices inside a group)
+constexpr int SW_KD = 64;     // sites per chunk = update slots per flush
 
+// Two-level delayed updates.  Within a chunk of KD sites the accepted Sherman-Morrison updates
+// are kept as G = G0 + U'V (slot j = j-th accept of the chunk):
+//   * the slot history U'[t][m], V[m][t] of thread t lives in the global arrays that the flush
+//     GEMM reads anyway (own-lane coalesced stores at accept, own-lane loads at group starts);
+//   * LDS keeps only what other threads need: UiT[m][s] = U'[site0+s][m], ViT[m][s] = V[m][site0+s]
+//     for the chunk's own sites, the current diagonal dg[s], the uniforms of the chunk;
+//   * the rows/columns of G at the 8 sites of the current GROUP are held current in registers:
+//     corrected once at the group start from all older slots (batched: one history load feeds 16
+//     FMAs), then updated eagerly at every accept inside the group (<= 14 FMAs).
+// An accept therefore costs O(1) per thread on the critical path instead of a 2*cnt loop.
 // Layout of the dynamic LDS region (doubles unless noted):
-//   Us[nb][KD][npad]   U'[t][m]  (thread t owns column t of every slot m)
-//   Vs[nb][KD][npad]   V[m][t]
-//   dg[2][KD]          current G[i,i] of the chunk's sites
-//   ul[KD]             the uniforms this chunk may consume, in draw order
-//   negv[KD]           negative determinant ratios met (sign-problem statistics)
-//   cs[KD], flip[KD] (int)  HS field of the chunk's sites at entry / accepted flags
-// NPAD > 0: compile-time row stride of the LDS update vectors (immediate offsets in the slot loop)
-template <int KD, int MAXT, int NPAD>
+//   UiT[nb][KD][KD], ViT[nb][KD][KD], dg[2][KD], ul[KD], negv[KD], cs[KD] (int), flip[KD] (int)
+template <int MAXT>
 __global__ __launch_bounds__(MAXT) void sweep_chunk_kernel(int n, int nb, int model, double *__restrict__ Gall,
                                                           long strideG, int8_t *__restrict__ conf_slice,
                                                           long conf_stride, int site0, int nsites,
@@ -62,15 +67,16 @@ __global__ __launch_bounds__(MAXT) void sweep_chunk_kernel(int n, int nb, int mo
                                                           long strideUV, SweepConsts sc, WalkerRng *rngs,
                                                           DevStats *stats, int check_sign)
 {
+    constexpr int KD = SW_KD;
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int npad = NPAD > 0 ? NPAD : ((n + 63) & ~63);
-    double *Us = sm;
-    double *Vs = Us + (size_t)nb * KD * npad;
-    double *dg = Vs + (size_t)nb * KD * npad;  // [2][KD]
+    const int npad = (n + 63) & ~63;
+    double *UiT = sm;
+    double *ViT = UiT + (size_t)nb * KD * KD;
+    double *dg = ViT + (size_t)nb * KD * KD;  // [2][KD]
     double *ul = dg + 2 * KD;
     double *negv = ul + KD;
     int *cs = (int *)(negv + KD);
-    int *flip = cs + KD;               // [KD] accepted sites (field is flipped at write-back)
+    int *flip = cs + KD;
 
     const int w = blockIdx.x;
     const int tid = threadIdx.x;
@@ -78,10 +84,10 @@ __global__ __launch_bounds__(MAXT) void sweep_chunk_kernel(int n, int nb, int mo
     const bool active = t < n;
     const int unit = w * nb + b;
     const double *__restrict__ G = Gall + (long)unit * strideG;
-    double *__restrict__ Uo = Uall + (long)unit * strideUV;
-    double *__restrict__ VTo = VTall + (long)unit * strideUV;
+    double *Uo = Uall + (long)unit * strideUV;   // slot m of thread t at Uo[t + n*m]
+    double *VTo = VTall + (long)unit * strideUV;
     int8_t *__restrict__ cw = conf_slice + (long)w * conf_stride;
-    double *usb = Us + (size_t)b * KD * npad, *vsb = Vs + (size_t)b * KD * npad;
+    double *uit = UiT + (size_t)b * KD * KD, *vit = ViT + (size_t)b * KD * KD;
 
     const int sl = t - site0;  // my index inside the chunk, if any
     const bool in_chunk = active && sl >= 0 && sl < nsites;
@@ -98,7 +104,7 @@ __global__ __launch_bounds__(MAXT) void sweep_chunk_kernel(int n, int nb, int mo
     const double g0 = sc.gamma[0], g1 = sc.gamma[1], e0 = sc.ebos[0], e1 = sc.ebos[1];
     const double du0 = sc.dup[0], du1 = sc.dup[1], dd0 = sc.ddn[0], dd1 = sc.ddn[1];
 
-    // G0[:, site] and G0[site, :] for one group of sites, prefetched one group ahead
+    // G0[:, site] and G0[site, :] for one group of sites, requested one group ahead
     double colr[SW_GROUP], rowr[SW_GROUP], coln[SW_GROUP], rown[SW_GROUP];
     auto fetch = [&](int s0, double (&cc)[SW_GROUP], double (&rr)[SW_GROUP]) {
 #pragma unroll
@@ -113,6 +119,31 @@ __global__ __launch_bounds__(MAXT) void sweep_chunk_kernel(int n, int nb, int mo
 
     for (int s0 = 0; s0 < nsites; s0 += SW_GROUP) {
         fetch(s0 + SW_GROUP, coln, rown);
+        // ---- group start: bring the group's rows/columns up to date with all slots of the chunk
+        {
+            const int cnt0 = __builtin_amdgcn_readfirstlane(cnt);
+            constexpr int HB = 16;  // history slots in flight: L2 latency is paid once per batch
+            for (int mb = 0; mb < cnt0; mb += HB) {
+                double hu[HB], hv[HB];
+#pragma unroll
+                for (int k = 0; k < HB; ++k) {
+                    const bool ok = active && mb + k < cnt0;
+                    hu[k] = ok ? Uo[t + (long)n * (mb + k)] : 0.0;
+                    hv[k] = ok ? VTo[t + (long)n * (mb + k)] : 0.0;
+                }
+#pragma unroll
+                for (int k = 0; k < HB; ++k) {
+                    if (mb + k < cnt0) {
+                        const double *ub = uit + (mb + k) * KD + s0, *vb = vit + (mb + k) * KD + s0;
+#pragma unroll
+                        for (int q = 0; q < SW_GROUP; ++q) {
+                            colr[q] += hu[k] * vb[q];   // G[t, site_q] += U'[t][m] V[m][site_q]
+                            rowr[q] += ub[q] * hv[k];   // G[site_q, t] += U'[site_q][m] V[m][t]
+                        }
+                    }
+                }
+            }
+        }
 #pragma unroll
         for (int q = 0; q < SW_GROUP; ++q) {
             const int s = s0 + q;
@@ -135,8 +166,6 @@ __global__ __launch_bounds__(MAXT) void sweep_chunk_kernel(int n, int nb, int mo
                     const double R0 = 1.0 + D0 * (1.0 - d0), R1 = 1.0 + D1 * (1.0 - d1);
                     detratio = R0 * R1;
                     p = detratio;
-                    x0 = R1 * D0;   // numerators only, see the accept branch
-                    x1 = R0 * D1;
                     r0s = R0; r1s = R1; d0s = D0; d1s = D1;
                 }
                 if (check_sign && detratio < 0.0) {
@@ -158,59 +187,44 @@ __global__ __launch_bounds__(MAXT) void sweep_chunk_kernel(int n, int nb, int mo
                         const double inv_div = 1.0 / detratio;
                         xb = (b == 0) ? (r1s * inv_div) * d0s : (r0s * inv_div) * d1s;
                     }
-                    // four accumulation chains over the slots (even/odd), pointers advanced by the
-                    // (compile-time when NPAD > 0) row stride: LDS reads get immediate offsets
-                    double c0 = colr[q], c1 = 0.0, r0 = rowr[q], r1 = 0.0;
-                    const double *pu_t = usb + t, *pu_i = usb + i, *pv_t = vsb + t, *pv_i = vsb + i;
-                    int m = 0;
-                    for (; m + 8 <= j; m += 8) {  // 32 LDS reads in flight before the first use
-                        double a_[8], b_[8], c_[8], d_[8];
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            a_[e] = pu_t[e * npad]; b_[e] = pv_i[e * npad];
-                            c_[e] = pu_i[e * npad]; d_[e] = pv_t[e * npad];
-                        }
-#pragma unroll
-                        for (int e = 0; e < 8; e += 2) {
-                            c0 += a_[e] * b_[e];         r0 += c_[e] * d_[e];
-                            c1 += a_[e + 1] * b_[e + 1]; r1 += c_[e + 1] * d_[e + 1];
-                        }
-                        pu_t += 8 * npad; pu_i += 8 * npad; pv_t += 8 * npad; pv_i += 8 * npad;
-                    }
-                    for (; m + 2 <= j; m += 2) {
-                        c0 += pu_t[0] * pv_i[0];        r0 += pu_i[0] * pv_t[0];
-                        c1 += pu_t[npad] * pv_i[npad];  r1 += pu_i[npad] * pv_t[npad];
-                        pu_t += 2 * npad; pu_i += 2 * npad; pv_t += 2 * npad; pv_i += 2 * npad;
-                    }
-                    for (; m < j; ++m) {
-                        c0 += pu_t[0] * pv_i[0];
-                        r0 += pu_i[0] * pv_t[0];
-                        pu_t += npad; pu_i += npad; pv_t += npad; pv_i += npad;
-                    }
-                    const double cold = c0 + c1, rowd = r0 + r1;
-                    const double ut = ((t == i) ? 1.0 : 0.0) - cold;  // IG = e_i - G[:,i]
-                    double newU = -(ut * xb), newV = rowd;
+                    const double ut = ((t == i) ? 1.0 : 0.0) - colr[q];  // IG = e_i - G[:,i]
+                    double newU = -(ut * xb), newV = rowr[q];
                     if (!active) { newU = 0.0; newV = 0.0; }
-                    usb[j * npad + t] = newU;
-                    vsb[j * npad + t] = newV;
-                    if (in_chunk && sl > s) dg[b * KD + sl] += newU * newV;  // sites <= s are done
+                    if (active) {  // slot history of this thread (also the flush GEMM's operands)
+                        Uo[t + (long)n * j] = newU;
+                        VTo[t + (long)n * j] = newV;
+                    }
+                    if (in_chunk) {
+                        uit[j * KD + sl] = newU;
+                        vit[j * KD + sl] = newV;
+                        if (sl > s) dg[b * KD + sl] += newU * newV;  // sites <= s are done
+                    }
                     // cs[s] itself must stay intact: waves drift apart between barriers (a rejected
                     // site has none) and a slower wave may not have read it yet for ITS proposal
                     if (tid == 0) flip[s] = 1;
                     ++cnt;
-                    __syncthreads();
+                    // LDS-only barrier: __syncthreads() would drain the history stores as well
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    // eager update of the rest of the group (static q' > q)
+                    {
+                        const double *ub = uit + j * KD + s0, *vb = vit + j * KD + s0;
+#pragma unroll
+                        for (int q2 = q + 1; q2 < SW_GROUP; ++q2) {
+                            colr[q2] += newU * vb[q2];
+                            rowr[q2] += ub[q2] * newV;
+                        }
+                    }
                 }
             }
         }
 #pragma unroll
         for (int q = 0; q < SW_GROUP; ++q) { colr[q] = coln[q]; rowr[q] = rown[q]; }
     }
-    // No global stores inside the site loop.  The update vectors leave LDS here, zero padded
-    // to KD slots so that the flush GEMM G0 += U' V always runs with K = KD.
+    // unused slots are zero padded so that the flush GEMM G0 += U' V always runs with K = KD
     if (active) {
-        for (int m = 0; m < KD; ++m) {
-            Uo[t + (long)n * m] = m < cnt ? usb[m * npad + t] : 0.0;
-            VTo[t + (long)n * m] = m < cnt ? vsb[m * npad + t] : 0.0;
+        for (int m = cnt; m < KD; ++m) {
+            Uo[t + (long)n * m] = 0.0;
+            VTo[t + (long)n * m] = 0.0;
         }
     }
     if (tid < nsites) cw[site0 + tid] = (int8_t)(flip[tid] ? -cs[tid] : cs[tid]);
@@ -223,14 +237,8 @@ __global__ __launch_bounds__(MAXT) void sweep_chunk_kernel(int n, int nb, int mo
     }
 }
 
-// chunk length: the update vectors of a chunk (2*KD*n doubles per block) live in LDS
-int sweep_kd(int n, int nb)
-{
-    const int npad = (n + 63) & ~63;
-    int kd = 32;
-    while (kd > 4 && (size_t)nb * 2 * kd * npad * sizeof(double) > 132 * 1024) kd >>= 1;
-    return kd;
-}
+// chunk length = update slots per flush (the history lives in global memory, LDS holds KD x KD tables)
+int sweep_kd(int n, int nb) { (void)n; (void)nb; return SW_KD; }
 
 hipError_t launch_sweep_chunk(int n, int nb, int n_walkers, int model, double *G, long strideG, int8_t *conf_slice,
                               long conf_stride, int site0, int nsites, double *Uout, double *VTout, long strideUV,
@@ -238,38 +246,23 @@ hipError_t launch_sweep_chunk(int n, int nb, int n_walkers, int model, double *G
 {
     const int npad = (n + 63) & ~63;
     const int threads = nb * npad;
-    const int kd = sweep_kd(n, nb);
-    if (threads > 1024 || nsites > kd) return hipErrorInvalidValue;
+    if (threads > 1024 || nsites > SW_KD) return hipErrorInvalidValue;
     dim3 grid(n_walkers), block(threads);
-    static const char *dbg = getenv("DQMC_DEBUG_SWEEP");
-    if (dbg) nsites = atoi(dbg) < nsites ? atoi(dbg) : nsites;
-    const size_t lds = ((size_t)nb * 2 * kd * npad + 6 * kd) * sizeof(double) + 64;
-#define SW_LAUNCH(KD, MT, NP)                                                                                     \
-    do {                                                                                                        \
-        static bool attr_set = false;                                                                           \
-        if (!attr_set) {                                                                                        \
-            (void)hipFuncSetAttribute((const void *)sweep_chunk_kernel<KD, MT, NP>,                             \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                  \
-            attr_set = true;                                                                                    \
-        }                                                                                                       \
-        hipLaunchKernelGGL((sweep_chunk_kernel<KD, MT, NP>), grid, block, lds, s, n, nb, model, G, strideG,     \
-                           conf_slice, conf_stride, site0, nsites, Uout, VTout, strideUV, sc, rng, stats,       \
-                           check_sign);                                                                         \
+    const size_t lds = ((size_t)nb * 2 * SW_KD * SW_KD + 6 * SW_KD) * sizeof(double) + 64;
+#define SW_LAUNCH(MT)                                                                                            \
+    do {                                                                                                         \
+        static bool attr_set = false;                                                                            \
+        if (!attr_set) {                                                                                         \
+            (void)hipFuncSetAttribute((const void *)sweep_chunk_kernel<MT>,                                      \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                   \
+            attr_set = true;                                                                                     \
+        }                                                                                                        \
+        hipLaunchKernelGGL((sweep_chunk_kernel<MT>), grid, block, lds, s, n, nb, model, G, strideG, conf_slice,  \
+                           conf_stride, site0, nsites, Uout, VTout, strideUV, sc, rng, stats, check_sign);       \
     } while (0)
-#define SW_BY_THREADS(KD)                             \
-    do {                                              \
-        if (threads <= 256) SW_LAUNCH(KD, 256, 0);    \
-        else if (threads <= 512) SW_LAUNCH(KD, 512, 0); \
-        else SW_LAUNCH(KD, 1024, 0);                  \
-    } while (0)
-    // the benchmark shapes (16x16 lattice) get the compile-time stride
-    if (npad == 256 && kd == 32 && threads == 256) SW_LAUNCH(32, 256, 256);
-    else if (npad == 256 && kd == 16 && threads == 512) SW_LAUNCH(16, 512, 256);
-    else if (kd == 32) SW_BY_THREADS(32);
-    else if (kd == 16) SW_BY_THREADS(16);
-    else if (kd == 8) SW_BY_THREADS(8);
-    else SW_BY_THREADS(4);
-#undef SW_BY_THREADS
+    if (threads <= 256) SW_LAUNCH(256);
+    else if (threads <= 512) SW_LAUNCH(512);
+    else SW_LAUNCH(1024);
 #undef SW_LAUNCH
     return hipGetLastError();
 }
