@@ -54,7 +54,7 @@ hipError_t launch_gemm(const GemmArgs &g, hipStream_t s);
 // column j of the factored matrix is original column pivot[j]).
 // Workspace of the cooperative (8 workgroups per matrix) QR: mailbox of n_units x 2 x 8 slots of
 // QR_COOP_SLOT doubles, n_units x 2 x 8 tags, an error flag (bounded spins), a launch counter.
-constexpr int QR_COOP_SLOT = 264;
+constexpr int QR_COOP_SLOT = 528;  // 264 packets of 16 bytes
 struct QrCoopWorkspace {
     double *mailbox = nullptr;
     unsigned long long *flags = nullptr;

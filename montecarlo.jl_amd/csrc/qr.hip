@@ -476,27 +476,45 @@ __global__ __launch_bounds__(QT_THREADS) void qr_tile256_kernel(int n, int nstep
 // replicated position tables pos[column], colat[position], so the reference's tie-break (first
 // maximum in position order, UDT.jl:151-168) and its swap bookkeeping (UDT.jl:219-231) are kept.
 //
-// One hand-off per step through a global mailbox (MI355X_MICROARCH.md, "Valid forms"): each
-// workgroup publishes {norm, position, column id} and the raw column of its best live column
-// with agent-scope relaxed (sc1, write-through) stores, drains them (s_waitcnt vmcnt(0)), passes a
-// workgroup barrier and only then stores its tag; consumers poll the 8 tags with sc1 loads from 8
-// lanes, then read headers and the winning column with sc1 loads.  Tags are epoch*1024 + step + 1
-// (no reset between launches), mailboxes are double buffered by step parity (the skew between
-// workgroups is at most one step, because a step cannot finish without everybody's tag).  Every
-// spin is bounded; a timeout raises a flag that the host reports.
+// One hand-off per step through a global mailbox, with SELF-VALIDATING packets (the LL protocol
+// of collective libraries): every double travels as two 8-byte words {low half, tag} and
+// {high half, tag}, each written with one agent-scope relaxed (sc1, write-through) 8-byte atomic
+// store and read with one sc1 8-byte atomic load, so a reader that sees the tag of this step has
+// the payload of this step -- no store drain, no separate flag, no second round trip for the
+// header.  Each workgroup publishes the raw column of its best live column plus a header
+// {norm, position, column id}; 8 lanes poll the 8 headers, then every thread polls its element of
+// the winning column.  Tags are epoch*1024 + step + 1 (no reset between launches; memory starts
+// zeroed and epoch >= 1), mailboxes are double buffered by step parity (the skew between
+// workgroups is at most one step, because a step cannot finish without everybody's header).
+// Every spin is bounded; a timeout raises a flag that the host reports.
 constexpr int QC_PARTS = 8;
-constexpr int QC_MB = 264;          // doubles per mailbox slot: 256 column entries + 8 header words
+constexpr int QC_MB = 264;          // packets (16 B) per mailbox slot: 256 column entries + header
 constexpr unsigned QC_SPIN_LIMIT = 4000000u;
 
-__device__ __forceinline__ void qc_store(double *p, double v)
+typedef unsigned long long qc_word;
+__device__ __forceinline__ void qc_put(qc_word *slot, double v, unsigned tag_lo, unsigned tag_hi)
 {
-    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v),
-                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+    __hip_atomic_store(slot, (bits & 0xffffffffull) | ((unsigned long long)tag_lo << 32), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(slot + 1, (bits >> 32) | ((unsigned long long)tag_hi << 32), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ double qc_load(const double *p)
+// spins until both halves carry their tags (tag_hi is compared under mask_hi); false on timeout
+__device__ __forceinline__ bool qc_get(const qc_word *slot, unsigned tag_lo, unsigned tag_hi, unsigned mask_hi,
+                                       double &v, unsigned &hi_word)
 {
-    return __longlong_as_double((long long)__hip_atomic_load(
-        reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    for (unsigned spins = 0; spins < QC_SPIN_LIMIT; ++spins) {
+        const unsigned long long a = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long b = __hip_atomic_load(slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(a >> 32) == tag_lo && (((unsigned)(b >> 32)) & mask_hi) == tag_hi) {
+            v = __longlong_as_double((long long)((a & 0xffffffffull) | (b << 32)));
+            hi_word = (unsigned)(b >> 32);
+            return true;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return false;
 }
 
 __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double *__restrict__ Aall, long strideA,
@@ -520,8 +538,8 @@ __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double
     double *__restrict__ A = Aall + (long)unit * strideA;
     double *__restrict__ tau = tauall + (long)unit * n;
     int *__restrict__ piv = pivall + (long)unit * n;
-    double *mb_unit = mailbox + (long)unit * 2 * QC_PARTS * QC_MB;
-    unsigned long long *fl_unit = flags + (long)unit * 2 * QC_PARTS;
+    qc_word *mb_unit = reinterpret_cast<qc_word *>(mailbox) + (long)unit * 2 * QC_PARTS * QC_MB * 2;
+    (void)flags;
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, rg = lane & 7, cg = lane >> 3;
     const int c = part + 8 * (8 * w + cg);  // my original column
@@ -542,7 +560,7 @@ __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double
 
     for (int j = 0; j < n; ++j) {
         const int par = j & 1;
-        const unsigned long long tag = epoch * 1024ull + (unsigned long long)j + 1ull;
+        const unsigned tag = (unsigned)(epoch * 1024ull + (unsigned long long)j + 1ull);
         // ---- my workgroup's best live column: larger norm first, then smaller position
         {
             double bn = -1.0;
@@ -569,31 +587,23 @@ __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double
             for (int k = 0; k < 32; ++k) dst[rg + 8 * k] = x[k];
         }
         __syncthreads();
-        // ---- publish: raw column + header, drained, then the tag
+        // ---- publish: raw column + header as tagged packets; nothing to wait for
         {
-            double *mb = mb_unit + (long)(par * QC_PARTS + part) * QC_MB;
-            qc_store(mb + tid, lbc >= 0 ? colbuf[tid] : 0.0);
-            if (tid == 0) {
-                qc_store(mb + 256, lbn);
-                qc_store(mb + 257, (double)lbp);
-                qc_store(mb + 258, (double)lbc);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            qc_word *mb = mb_unit + (long)(par * QC_PARTS + part) * QC_MB * 2;
+            qc_put(mb + 2 * tid, lbc >= 0 ? colbuf[tid] : 0.0, tag, tag);
+            // header: norm in the payload, {position, column id} ride in the low half of the second tag
             if (tid == 0)
-                __hip_atomic_store(fl_unit + par * QC_PARTS + part, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                qc_put(mb + 2 * 256, lbn, tag, (tag << 16) | ((unsigned)(lbp & 0xff) << 8) | (unsigned)(lbc & 0xff));
         }
-        // ---- collect: 8 lanes poll the 8 tags and fetch the headers behind them
+        // ---- collect: 8 lanes poll the 8 headers
         if (tid < QC_PARTS) {
-            unsigned spins = 0;
-            while (__hip_atomic_load(fl_unit + par * QC_PARTS + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tag) {
-                if (++spins > QC_SPIN_LIMIT) { s_abort = 1; break; }
-                __builtin_amdgcn_s_sleep(2);
-            }
-            const double *mb = mb_unit + (long)(par * QC_PARTS + tid) * QC_MB;
-            hdr_norm[tid] = qc_load(mb + 256);
-            hdr_pos[tid] = (int)qc_load(mb + 257);
-            hdr_col[tid] = (int)qc_load(mb + 258);
+            double hn = 0.0;
+            unsigned hw = 0;
+            const qc_word *mb = mb_unit + (long)(par * QC_PARTS + tid) * QC_MB * 2;
+            if (!qc_get(mb + 2 * 256, tag, tag << 16, 0xffff0000u, hn, hw)) s_abort = 1;
+            hdr_norm[tid] = hn;
+            hdr_pos[tid] = (int)((hw >> 8) & 0xff);
+            hdr_col[tid] = hn < 0.0 ? -1 : (int)(hw & 0xff);  // norm -1: that workgroup has no live column
         }
         __syncthreads();
         if (s_abort) break;
@@ -605,11 +615,17 @@ __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double
                 maxval = hdr_norm[q]; jm = hdr_pos[q]; cm = hdr_col[q]; wpart = q;
             }
         if (cm < 0) { cm = colat[j]; jm = j; maxval = 0.0; wpart = cm & 7; }  // nothing live: cannot happen for j < n
-        // ---- the winning column (sc1 loads), reflector (UDT.jl:133-148), output column j
-        const double cv = qc_load(mb_unit + (long)(par * QC_PARTS + wpart) * QC_MB + tid);
+        // ---- the winning column (tagged packets), reflector (UDT.jl:133-148), output column j
+        double cv = 0.0;
+        {
+            unsigned hw;
+            if (!qc_get(mb_unit + (long)(par * QC_PARTS + wpart) * QC_MB * 2 + 2 * tid, tag, tag, 0xffffffffu, cv, hw))
+                s_abort = 1;
+        }
         const double rootn = sqrt(maxval);  // overlaps the column load
         colbuf[tid] = cv;
         __syncthreads();
+        if (s_abort) break;
         const double xi1 = colbuf[j];
         double tj = 0.0, nu = 0.0, xi = 1.0;
         if (maxval != 0.0) {
