@@ -213,7 +213,7 @@ static int alloc_qr_workspace(dqmc_handle *h)
     if (h->n > 256) return 0;
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, h->p.device_id));
-    const size_t slots = (size_t)((h->units + 7) / 8) * 8 * 2 * 8;
+    const size_t slots = (size_t)((h->units + 7) / 8) * 8 * 2 * 32;  // units x parity x 32 wave agents
     CHK(dalloc(h, &h->qr_ws.mailbox, slots * QR_COOP_SLOT));
     CHK(dalloc(h, &h->qr_ws.flags, slots));
     CHK(dalloc(h, &h->qr_ws.errflag, (size_t)1));

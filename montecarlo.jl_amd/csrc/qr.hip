@@ -517,6 +517,46 @@ __device__ __forceinline__ bool qc_get(const qc_word *slot, unsigned tag_lo, uns
     return false;
 }
 
+// wave-wide reductions on DPP (no LDS, no ds_bpermute): results are wave-uniform
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+__device__ __forceinline__ double dpp_self_f64(double x)
+{
+    // lanes without a valid source (or in masked rows) get their own value back
+    const int lo = __double2loint(x), hi = __double2hiint(x);
+    return __hiloint2double(__builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, BANK_MASK, false),
+                            __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, BANK_MASK, false));
+}
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+__device__ __forceinline__ unsigned dpp_self_u32(unsigned x)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, CTRL, ROW_MASK, BANK_MASK, false);
+}
+// maximum over the wave, returned wave-uniform.  FROM = 8: the value is already equal inside
+// groups of 8 consecutive lanes (only lane bits 3..5 need combining)
+template <int FROM>
+__device__ __forceinline__ double wave_max_f64(double v)
+{
+    if (FROM <= 1) v = fmax(v, dpp_self_f64<0x111>(v));  // row_shr:1
+    if (FROM <= 2) v = fmax(v, dpp_self_f64<0x112>(v));  // row_shr:2
+    if (FROM <= 4) v = fmax(v, dpp_self_f64<0x114>(v));  // row_shr:4
+    v = fmax(v, dpp_self_f64<0x118>(v));                 // row_shr:8  -> lane 15 of each row
+    v = fmax(v, dpp_self_f64<0x142, 0xa>(v));            // row_bcast:15 into rows 1, 3
+    v = fmax(v, dpp_self_f64<0x143, 0xc>(v));            // row_bcast:31 into rows 2, 3 -> lane 63
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63),
+                            __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+template <int FROM>
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v)
+{
+    if (FROM <= 1) v = min(v, dpp_self_u32<0x111>(v));
+    if (FROM <= 2) v = min(v, dpp_self_u32<0x112>(v));
+    if (FROM <= 4) v = min(v, dpp_self_u32<0x114>(v));
+    v = min(v, dpp_self_u32<0x118>(v));
+    v = min(v, dpp_self_u32<0x142, 0xa>(v));
+    v = min(v, dpp_self_u32<0x143, 0xc>(v));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double *__restrict__ Aall, long strideA,
                                                      double *__restrict__ tauall, int *__restrict__ pivall,
                                                      double *mailbox, unsigned long long *flags,
@@ -563,16 +603,13 @@ __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double
         const unsigned tag = (unsigned)(epoch * 1024ull + (unsigned long long)j + 1ull);
         // ---- my workgroup's best live column: larger norm first, then smaller position
         {
-            double bn = -1.0;
-            int bp = 0x7fffffff, bc = -1;
-            if (c < n && pos[c] >= j) { bn = nrm; bp = pos[c]; bc = c; }
-#pragma unroll
-            for (int off = 8; off < 64; off <<= 1) {
-                const double on = __shfl_xor(bn, off, 64);
-                const int op = __shfl_xor(bp, off, 64), oc = __shfl_xor(bc, off, 64);
-                if (on > bn || (on == bn && op < bp)) { bn = on; bp = op; bc = oc; }
-            }
-            if (lane == 0) { wc_norm[w] = bn; wc_pos[w] = bp; wc_col[w] = bc; }
+            const bool live = c < n && pos[c] >= j;
+            const double bn = wave_max_f64<8>(live ? nrm : -1.0);
+            const unsigned mp = live ? (unsigned)pos[c] : 0xffffffffu;
+            const unsigned bp = wave_min_u32<8>((live && nrm == bn) ? mp : 0xffffffffu);
+            int bc = -1;
+            if (bn >= 0.0) bc = __builtin_amdgcn_readlane(c, __ffsll((long long)__ballot(live && mp == bp)) - 1);
+            if (lane == 0) { wc_norm[w] = bn; wc_pos[w] = (int)(bp & 0x7fffffffu); wc_col[w] = bc; }
         }
         __syncthreads();
         double lbn = wc_norm[0];
@@ -655,19 +692,19 @@ __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double
         // ---- apply H_j to my column if it is still live (reflectorApply!, UDT.jl:32-50); fresh norm
         if (c < n && pos[c] > j) {
             const double *vq = vperm + rg * QT_VS;
+            double2 vv[16];  // the reflector stays in registers for the second pass (LDS pipe is shared by 4 waves)
             double d0 = 0.0, d1 = 0.0;
 #pragma unroll
             for (int k = 0; k < 32; k += 2) {
-                const double2 v2 = *reinterpret_cast<const double2 *>(vq + k);
-                d0 += v2.x * x[k];
-                d1 += v2.y * x[k + 1];
+                vv[k >> 1] = *reinterpret_cast<const double2 *>(vq + k);
+                d0 += vv[k >> 1].x * x[k];
+                d1 += vv[k >> 1].y * x[k + 1];
             }
             const double wv = sum8(d0 + d1) * tj;
             double n0 = 0.0, n1 = 0.0;
 #pragma unroll
             for (int k = 0; k < 32; k += 2) {
-                const double2 v2 = *reinterpret_cast<const double2 *>(vq + k);
-                const double y0 = x[k] - v2.x * wv, y1 = x[k + 1] - v2.y * wv;
+                const double y0 = x[k] - vv[k >> 1].x * wv, y1 = x[k + 1] - vv[k >> 1].y * wv;
                 x[k] = y0;
                 x[k + 1] = y1;
                 n0 += (rg + 8 * k > j ? 1.0 : 0.0) * (y0 * y0);
