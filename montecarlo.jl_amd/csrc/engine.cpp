@@ -162,8 +162,21 @@ static MatRef U_(dqmc_handle *h, const double *p) { return mat(p, h->nn, h->n); 
 static MatRef C_(dqmc_handle *h, const double *p) { return mat(p, 0, h->n, h->nn); }     // shared constant, per block
 static int run_gemm(dqmc_handle *h, const GemmArgs &g)
 {
-    Timed t(h, DQMC_K_GEMM);
-    HIPCHK(launch_gemm(g, h->stream));
+    if (!h->timing) {
+        HIPCHK(launch_gemm(g, h->stream));
+        return 0;
+    }
+    // kernel-only duration: the events are attached to the dispatch itself (no launch gap inside)
+    auto get = [&]() {
+        hipEvent_t e;
+        if (!h->pool.empty()) { e = h->pool.back(); h->pool.pop_back(); }
+        else (void)hipEventCreate(&e);
+        return e;
+    };
+    hipEvent_t a = get(), b = get();
+    HIPCHK(launch_gemm(g, h->stream, a, b));
+    h->pending.push_back({a, b, DQMC_K_GEMM});
+    if (h->pending.size() >= 2048) CHK(timing_drain(h));
     return 0;
 }
 // exp(sign*lambda*conf[:,slice]) for block 0, exp(-sign*lambda*conf) for block 1

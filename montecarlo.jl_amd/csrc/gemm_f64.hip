@@ -12,6 +12,7 @@
 // so that the accumulator's lane index runs along m, the contiguous direction of
 // column-major C: stores are 128-byte segments.
 #include "kernels.h"
+#include <hip/hip_ext.h>
 
 namespace dqmc {
 
@@ -181,18 +182,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, int tiles_m, int 
     }
 }
 
-hipError_t launch_gemm(const GemmArgs &g, hipStream_t s)
+hipError_t launch_gemm(const GemmArgs &g, hipStream_t s, hipEvent_t start, hipEvent_t stop)
 {
     const int tm = (g.M + BM - 1) / BM, tn = (g.N + BN - 1) / BN;
     const int groups = (g.n_units + 7) / 8;
     dim3 grid(groups * 8 * tm * tn), block(256);
+#define GEMM_LAUNCH(TA, TB) hipExtLaunchKernelGGL((gemm_kernel<TA, TB>), grid, block, 0, s, start, stop, 0, g, tm, tn)
     if (g.transA) {
-        if (g.transB) hipLaunchKernelGGL((gemm_kernel<true, true>), grid, block, 0, s, g, tm, tn);
-        else hipLaunchKernelGGL((gemm_kernel<true, false>), grid, block, 0, s, g, tm, tn);
+        if (g.transB) GEMM_LAUNCH(true, true);
+        else GEMM_LAUNCH(true, false);
     } else {
-        if (g.transB) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, block, 0, s, g, tm, tn);
-        else hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, 0, s, g, tm, tn);
+        if (g.transB) GEMM_LAUNCH(false, true);
+        else GEMM_LAUNCH(false, false);
     }
+#undef GEMM_LAUNCH
     return hipGetLastError();
 }
 

@@ -46,7 +46,9 @@ struct GemmArgs {
     double ident;   // added on the diagonal
     int beta;       // 0: overwrite, 1: accumulate into C
 };
-hipError_t launch_gemm(const GemmArgs &g, hipStream_t s);
+// start/stop (optional): events that take the dispatch's own begin/end timestamps (hipExtLaunchKernelGGL),
+// i.e. the kernel-only duration a profiler's kernel trace reports
+hipError_t launch_gemm(const GemmArgs &g, hipStream_t s, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
 
 // Column-pivoted Householder QR, in place (udt_AVX_pivot! "QR decomposition" loop,
 // src/linalg/UDT.jl:212-246).  On exit A holds R on/above the diagonal and the
