@@ -177,6 +177,18 @@ int dqmc_correlations_size(dqmc_handle *h, size_t *n_doubles);
 int dqmc_get_correlations(dqmc_handle *h, double *host_out);
 int dqmc_export_correlations(dqmc_handle *h, void *device_out);
 
+/* pc_kernel over EachLocalQuadByDistance{K} (measurements/measurements.jl:199-214, generic.jl:287-290,
+ * 341-349, src/lattices/lattice_iterators.jl:258-318; HubbardModelAttractive.jl:243-245):
+ * trg_of[src + n*k] (0-based, -1 = none) is the site reached from src in the k-th shortest direction,
+ * k < K, i.e. the (dir, trg) lists the iterator builds from EachSitePairByDistance.  Accumulator layout:
+ * [n_dirs x K x K] in Julia's column-major order of output[dir12, dir1, dir2], already divided by
+ * n_sites, then [samples].  Requires dqmc_set_pair_directions. */
+int dqmc_set_local_targets(dqmc_handle *h, const int32_t *trg_of, int32_t K);
+int dqmc_accumulate_pairing(dqmc_handle *h);
+int dqmc_pairing_size(dqmc_handle *h, size_t *n_doubles);
+int dqmc_get_pairing(dqmc_handle *h, double *host_out);
+int dqmc_export_pairing(dqmc_handle *h, void *device_out);
+
 /* ---- batched linalg primitives (unit parity with test/slice_matrices.jl) --
  * host in / host out, `batch` independent n x n problems, run on device_id.  */
 /* vmul! family (src/linalg/general.jl:7-56): C = op(A)*op(B); transa/transb 0|1 */

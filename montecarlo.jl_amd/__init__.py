@@ -8,7 +8,8 @@ from ._lib import DQMCError, lib  # noqa: F401
 from .configurations import (CompressedConf, ConfigRecorder, Discarder, compress,  # noqa: F401
                              decompress)
 from . import lattices  # noqa: F401
-from .lattices import Chain, EachSitePairByDistance, SquareLattice, build_checkerboard  # noqa: F401
+from .lattices import (Chain, EachLocalQuadByDistance, EachSitePairByDistance, SquareLattice,  # noqa: F401
+                       build_checkerboard)
 from .models import (HubbardModel, HubbardModelAttractive, HubbardModelRepulsive,  # noqa: F401
                      rand_conf)
 from .sharding import reduce_accumulators, walker_range, walker_seeds  # noqa: F401

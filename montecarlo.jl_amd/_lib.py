@@ -83,6 +83,11 @@ SIGNATURES = {
     "dqmc_correlations_size": (C.c_int, [_H, C.POINTER(C.c_size_t)]),
     "dqmc_get_correlations": (C.c_int, [_H, _dp]),
     "dqmc_export_correlations": (C.c_int, [_H, C.c_void_p]),
+    "dqmc_set_local_targets": (C.c_int, [_H, C.POINTER(C.c_int32), C.c_int32]),
+    "dqmc_accumulate_pairing": (C.c_int, [_H]),
+    "dqmc_pairing_size": (C.c_int, [_H, C.POINTER(C.c_size_t)]),
+    "dqmc_get_pairing": (C.c_int, [_H, _dp]),
+    "dqmc_export_pairing": (C.c_int, [_H, C.c_void_p]),
     "dqmc_vmul": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _dp, _dp, _dp]),
     "dqmc_udt_pivot": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _dp, _dp, _dp, _i64p, C.c_int32]),
     "dqmc_rdivp": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _dp, _dp, _i64p]),

@@ -47,6 +47,10 @@ struct dqmc_handle {
     int n_dirs = 0;
     int *dir_ptr = nullptr, *pair_src = nullptr, *pair_trg = nullptr;
     double *corr_per_walker = nullptr, *corr_acc = nullptr;
+    int K_loc = 0;                  // EachLocalQuadByDistance{K}
+    int *trg_of = nullptr;          // [K][n]
+    size_t pc_n = 0;
+    double *pc_per_walker = nullptr, *pc_acc = nullptr;
     size_t corr_n = 0;
     int current_slice = 0, direction = 0;
     bool prepared = false;
@@ -1013,6 +1017,59 @@ int dqmc_export_correlations(dqmc_handle *h, void *device_out)
     HIPCHK(hipStreamSynchronize(h->stream));
     return DQMC_OK;
 }
+// EachLocalQuadByDistance{K}(lattice) (lattice_iterators.jl:264-318) as a target table
+int dqmc_set_local_targets(dqmc_handle *h, const int32_t *trg_of, int32_t K)
+{
+    ENTER(h);
+    const int n = h->n;
+    if (!h->n_dirs) return fail(h, DQMC_ERR_STATE, "call dqmc_set_pair_directions first");
+    if (!trg_of || K < 1 || K > h->n_dirs) return fail(h, DQMC_ERR_INVALID, "bad target table");
+    for (size_t i = 0; i < (size_t)n * K; ++i)
+        if (trg_of[i] < -1 || trg_of[i] >= n) return fail(h, DQMC_ERR_INVALID, "target index out of range");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->K_loc = K;
+    h->pc_n = (size_t)h->n_dirs * K * K + 1;
+    CHK(dalloc(h, &h->trg_of, (size_t)n * K));
+    CHK(dalloc(h, &h->pc_per_walker, (size_t)h->W * (h->pc_n - 1)));
+    CHK(dalloc(h, &h->pc_acc, h->pc_n));
+    HIPCHK(hipMemcpy(h->trg_of, trg_of, sizeof(int) * n * K, hipMemcpyHostToDevice));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return DQMC_OK;
+}
+int dqmc_accumulate_pairing(dqmc_handle *h)
+{
+    ENTER(h); NEED_PREPARED(h);
+    if (!h->K_loc) return fail(h, DQMC_ERR_STATE, "call dqmc_set_local_targets first");
+    CHK(true_greens(h, h->greens));
+    {
+        Timed t(h, DQMC_K_MISC);
+        HIPCHK(launch_pairing(h->n, h->nb, h->W, h->tmp2, h->nn, h->dir_ptr, h->pair_src, h->pair_trg, h->n_dirs,
+                              h->K_loc, h->trg_of, h->pc_per_walker, h->pc_acc, h->stream));
+    }
+    return DQMC_OK;
+}
+int dqmc_pairing_size(dqmc_handle *h, size_t *n)
+{
+    if (!h || !n) return DQMC_ERR_INVALID;
+    *n = h->pc_n;
+    return DQMC_OK;
+}
+int dqmc_get_pairing(dqmc_handle *h, double *host_out)
+{
+    ENTER(h);
+    if (!h->K_loc) return fail(h, DQMC_ERR_STATE, "call dqmc_set_local_targets first");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(host_out, h->pc_acc, h->pc_n * sizeof(double), hipMemcpyDeviceToHost));
+    return DQMC_OK;
+}
+int dqmc_export_pairing(dqmc_handle *h, void *device_out)
+{
+    ENTER(h);
+    if (!h->K_loc) return fail(h, DQMC_ERR_STATE, "call dqmc_set_local_targets first");
+    HIPCHK(hipMemcpyAsync(device_out, h->pc_acc, h->pc_n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return DQMC_OK;
+}
 int dqmc_accumulator_size(dqmc_handle *h, size_t *n)
 {
     if (!h || !n) return DQMC_ERR_INVALID;
@@ -1024,6 +1081,7 @@ int dqmc_reset_accumulators(dqmc_handle *h)
     ENTER(h);
     HIPCHK(hipMemsetAsync(h->acc, 0, h->acc_n * sizeof(double), h->stream));
     if (h->corr_acc) HIPCHK(hipMemsetAsync(h->corr_acc, 0, h->corr_n * sizeof(double), h->stream));
+    if (h->pc_acc) HIPCHK(hipMemsetAsync(h->pc_acc, 0, h->pc_n * sizeof(double), h->stream));
     return DQMC_OK;
 }
 int dqmc_get_accumulators(dqmc_handle *h, double *host_out)

@@ -125,6 +125,11 @@ hipError_t launch_mfma_peak(int iters, int blocks, double *sink, hipStream_t s);
 hipError_t launch_correlations(int n, int nb, int model, int n_walkers, const double *G, long stride_unit,
                                const int *dir_ptr, const int *pair_src, const int *pair_trg, int n_dirs,
                                double *per_walker, double *acc, hipStream_t s);
+// pc_kernel over EachLocalQuadByDistance{K}: trg_of[src + n*k] = target of src in direction k (< K), -1 if none;
+// per_walker [walkers][n_dirs*K*K], acc [n_dirs*K*K + 1] (Julia layout [dir12, dir1, dir2], then the sample count)
+hipError_t launch_pairing(int n, int nb, int n_walkers, const double *G, long stride_unit, const int *dir_ptr,
+                          const int *pair_src, const int *pair_trg, int n_dirs, int K, const int *trg_of,
+                          double *per_walker, double *acc, hipStream_t s);
 // HS field <-> Julia BitArray chunks (compress / decompress, HubbardModel.jl:56-59)
 hipError_t launch_conf_pack(const int8_t *conf, size_t n_elem, unsigned long long *chunks, hipStream_t s);
 hipError_t launch_conf_unpack(const unsigned long long *chunks, size_t n_elem, int8_t *conf, hipStream_t s);

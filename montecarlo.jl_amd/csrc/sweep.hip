@@ -440,6 +440,65 @@ hipError_t launch_correlations(int n, int nb, int model, int n_walkers, const do
     return hipGetLastError();
 }
 
+// pc_kernel over EachLocalQuadByDistance{K} (measurements.jl:208-214, generic.jl:341-349,
+// lattice_iterators.jl:264-318; attractive override HubbardModelAttractive.jl:243-245):
+//   out[dir12, dir1, dir2] += G[src1, src2] * G[trg1+N, trg2+N] - G[src1, trg2+N] * G[trg1+N, src2]
+// summed over all (src1, src2) with direction dir12 and the targets trg_k(src) of src in the K
+// shortest directions.  With block-diagonal G (both Hubbard models here) the second product is 0 and
+// the first is G_up[src1,src2] * G_dn[trg1,trg2] (attractive: G_dn = G_up).  One workgroup owns one
+// (direction, walker) and reduces every (dir1, dir2) in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void pairing_kernel(int n, int nb, const double *__restrict__ G, long stride_unit,
+                                                     const int *__restrict__ dir_ptr,
+                                                     const int *__restrict__ pair_src,
+                                                     const int *__restrict__ pair_trg, int n_dirs, int K,
+                                                     const int *__restrict__ trg_of,
+                                                     double *__restrict__ per_walker, long per_stride)
+{
+    __shared__ double red[256];
+    const int d = blockIdx.x, w = blockIdx.y, tid = threadIdx.x;
+    const double *G1 = G + (long)(w * nb) * stride_unit;
+    const double *G2 = nb == 2 ? G1 + stride_unit : G1;
+    for (int k2 = 0; k2 < K; ++k2)
+        for (int k1 = 0; k1 < K; ++k1) {
+            double s = 0.0;
+            for (int q = dir_ptr[d] + tid; q < dir_ptr[d + 1]; q += 256) {
+                const int s1 = pair_src[q], s2 = pair_trg[q];
+                const int t1 = trg_of[s1 + n * k1], t2 = trg_of[s2 + n * k2];
+                if (t1 >= 0 && t2 >= 0) s += G1[s1 + (long)n * s2] * G2[t1 + (long)n * t2];
+            }
+            red[tid] = s;
+            __syncthreads();
+            for (int off = 128; off > 0; off >>= 1) {
+                if (tid < off) red[tid] += red[tid + off];
+                __syncthreads();
+            }
+            if (tid == 0)  // finish!: / N (generic.jl:287-290); Julia layout [dir12, dir1, dir2]
+                per_walker[(long)w * per_stride + d + (long)n_dirs * (k1 + K * k2)] = red[0] / (double)n;
+            __syncthreads();
+        }
+}
+__global__ void pairing_reduce_kernel(int n_walkers, long total, const double *__restrict__ per_walker,
+                                      double *__restrict__ acc)
+{
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        double s = 0.0;
+        for (int w = 0; w < n_walkers; ++w) s += per_walker[(long)w * total + e];
+        acc[e] += s;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) acc[total] += (double)n_walkers;
+}
+hipError_t launch_pairing(int n, int nb, int n_walkers, const double *G, long stride_unit, const int *dir_ptr,
+                          const int *pair_src, const int *pair_trg, int n_dirs, int K, const int *trg_of,
+                          double *per_walker, double *acc, hipStream_t s)
+{
+    const long total = (long)n_dirs * K * K;
+    hipLaunchKernelGGL(pairing_kernel, dim3(n_dirs, n_walkers), dim3(256), 0, s, n, nb, G, stride_unit, dir_ptr,
+                       pair_src, pair_trg, n_dirs, K, trg_of, per_walker, total);
+    hipLaunchKernelGGL(pairing_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, n_walkers, total,
+                       per_walker, acc);
+    return hipGetLastError();
+}
+
 // compress(mc, model, conf) = BitArray(conf .== 1) (HubbardModel.jl:56-59): Julia's BitArray keeps
 // element i (1-based, column-major) in bit (i-1) % 64 of chunk (i-1) / 64.  One wave packs one chunk.
 __global__ void conf_pack_kernel(const int8_t *__restrict__ conf, size_t n_elem, unsigned long long *__restrict__ chunks)

@@ -346,6 +346,27 @@ class DQMC:
         res["count"] = cnt
         return res
 
+    # ---- pairing_correlation (measurements.jl:199-214) over EachLocalQuadByDistance{K}
+    def set_local_targets(self, iterator):
+        """hand the (dir, trg) lists of EachLocalQuadByDistance{K} to the device; the pair
+        directions of the same lattice are set with it"""
+        self.set_pair_directions(iterator.pairs_by_dir)
+        tab = np.asfortranarray(iterator.trg_of.astype(np.int32))  # [src, k] -> trg_of[src + n*k]
+        self._K = iterator.K
+        self._c(lib().dqmc_set_local_targets(self._h, tab.ctypes.data_as(C.POINTER(C.c_int32)), self._K))
+
+    def accumulate_pairing(self):
+        self._c(lib().dqmc_accumulate_pairing(self._h))
+
+    def pairing(self):
+        """-> (mean of output[dir12, dir1, dir2] as pushed by finish!, sample count)"""
+        n = C.c_size_t()
+        self._c(lib().dqmc_pairing_size(self._h, C.byref(n)))
+        out = np.zeros(n.value)
+        self._c(lib().dqmc_get_pairing(self._h, dptr(out)))
+        cnt = out[-1]
+        return out[:-1].reshape((self._ndirs, self._K, self._K), order="F") / cnt, cnt
+
     # ---- instrumentation
     def timing_enable(self, on=True):
         self._c(lib().dqmc_timing_enable(self._h, int(on)))

@@ -146,3 +146,53 @@ class EachSitePairByDistance:
         for d, prs in enumerate(self.pairs):
             for s, t in prs:
                 yield d + 1, s, t
+
+
+class EachLocalQuadByDistance:
+    """EachLocalQuadByDistance{K}(lattice) (src/lattices/lattice_iterators.jl:258-353): quadruples
+    (src1, trg1, src2, trg2) where trg_k is reached from src_k in one of the K shortest directions,
+    grouped by (dir12, dir1, dir2) with dir12 the direction index of the pair (src1, src2).
+    `trg_from_src[src-1]` lists the 1-based (dir, trg) of a source in the reference's order;
+    `trg_of[src-1, k]` is the 0-based target in direction k (-1 if the site has none; sites of a
+    Bravais lattice have exactly one per direction)."""
+
+    def __init__(self, lattice, K=None, pairs=None):
+        self.pairs_by_dir = pairs if pairs is not None else EachSitePairByDistance(lattice)
+        n = len(lattice)
+        if K is None:  # pairing(): K = 1 + length(neighbors(lattice, 1)) (measurements.jl:199-204)
+            K = 1 + lattice.neighs.shape[0]
+        if K > self.pairs_by_dir.ndirections():
+            raise ValueError("K exceeds the number of directions of the lattice")
+        self.K = K
+        self.trg_from_src = [[] for _ in range(n)]
+        for d in range(K):
+            for src, trg in self.pairs_by_dir.pairs[d]:
+                self.trg_from_src[src - 1].append((d + 1, trg))
+        self.N = sum(len(x) for x in self.trg_from_src) ** 2
+        self.trg_of = -np.ones((n, K), dtype=np.int32)
+        for src, lst in enumerate(self.trg_from_src):
+            for d, trg in lst:
+                if self.trg_of[src, d - 1] >= 0:
+                    raise ValueError("more than one target per direction: lattice with a basis is not supported")
+                self.trg_of[src, d - 1] = trg - 1
+
+    def __len__(self):
+        return self.N
+
+    def ndirections(self):
+        return (self.pairs_by_dir.ndirections(), self.K, self.K)
+
+    def __iter__(self):
+        """(lin, src1, trg1, src2, trg2), lin the 1-based linear index of (dir12, dir1, dir2)"""
+        nd, K = self.pairs_by_dir.ndirections(), self.K
+        for d2 in range(K):
+            for d1 in range(K):
+                for d12 in range(nd):
+                    lin = 1 + d12 + nd * (d1 + K * d2)
+                    for src1, src2 in self.pairs_by_dir.pairs[d12]:
+                        for dir1, trg1 in self.trg_from_src[src1 - 1]:
+                            if dir1 != d1 + 1:
+                                continue
+                            for dir2, trg2 in self.trg_from_src[src2 - 1]:
+                                if dir2 == d2 + 1:
+                                    yield lin, src1, trg1, src2, trg2

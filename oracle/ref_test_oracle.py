@@ -100,7 +100,7 @@ def _fermion_ops(n_modes):
     return ops
 
 
-def ed_hubbard_greens(neighs, n_sites, U, t, mu, beta):
+def ed_hubbard_greens(neighs, n_sites, U, t, mu, beta, return_state=False):
     """G[(s1,i),(s2,j)] = <c_{i,s1} c^dagger_{j,s2}> for
     H = -t sum_{src, trg in neighs[:,src], sigma} c^dag_{trg} c_{src}
         + U sum_i (n_up-1/2)(n_dn-1/2) - mu sum_i n_i      (ED.jl:68-120);
@@ -123,6 +123,8 @@ def ed_hubbard_greens(neighs, n_sites, U, t, mu, beta):
     w = w - w.min()
     rho = (V * np.exp(-beta * w)) @ V.T
     Z = np.trace(rho)
+    if return_state:
+        return rho / Z, c, cd
     G = np.zeros((nm, nm))
     for a_ in range(nm):
         for b_ in range(nm):
@@ -240,3 +242,41 @@ def equal_time_correlations(blocks, L, attractive):
     out["My"] = z.copy() if attractive else np.array([G[i + N, i] - G[i, i + N] for i in range(N)])
     out["Mz"] = z.copy() if attractive else np.array([G[i + N, i + N] - G[i, i] for i in range(N)])
     return out
+
+
+# --------------------------------------------------------------------------
+# pairing correlation: pc_kernel (measurements.jl:208-214) over EachLocalQuadByDistance{K}
+# (lattice_iterators.jl:264-318, apply!/finish! generic.jl:287-290,341-349)
+def pc_kernel(G, N, src1, trg1, src2, trg2):
+    """<Delta_v(src1, trg1) Delta_v^dagger(src2, trg2)> by Wick's theorem, 0-based sites"""
+    return G[src1, src2] * G[trg1 + N, trg2 + N] - G[src1, trg2 + N] * G[trg1 + N, src2]
+
+
+def ed_pairing(rho, c, cd, N, src1, trg1, src2, trg2):
+    """the same expectation value taken directly in the Fock space:
+    Delta(i, j) = c_{i,up} c_{j,dn},  Delta^dagger(i, j) = c^dag_{j,dn} c^dag_{i,up}"""
+    op = c[src1] @ c[N + trg1] @ cd[N + trg2] @ cd[src2]
+    return np.trace(rho @ op)
+
+
+def pairing_correlation(blocks, L, attractive, K):
+    """output[dir12, dir1, dir2] as pushed by finish!, from the block Green's functions of one
+    configuration.  The (dir, trg) lists are rebuilt here from square_pair_directions."""
+    N = L * L
+    G = full_greens(blocks)
+    dirs, table = square_pair_directions(L)
+    nd = len(dirs)
+    trg = [[[t for t in range(N) if table[s, t] == k] for k in range(K)] for s in range(N)]
+    out = np.zeros((nd, K, K))
+    for s1 in range(N):
+        for s2 in range(N):
+            d12 = table[s1, s2]
+            for k1 in range(K):
+                for t1 in trg[s1][k1]:
+                    for k2 in range(K):
+                        for t2 in trg[s2][k2]:
+                            if attractive:  # HubbardModelAttractive.jl:243-245
+                                out[d12, k1, k2] += G[s1, s2] * G[t1, t2]
+                            else:
+                                out[d12, k1, k2] += pc_kernel(G, N, s1, t1, s2, t2)
+    return out / N

@@ -140,3 +140,39 @@ def test_pair_iterator_contracts(mc_amd, R):
             dv = it.directions[d - 1]
             assert (i1 - i2 - dv[0]) % L == 0 and (j1 - j2 - dv[1]) % L == 0
     assert list(mc_amd.EachSitePairByDistance(mc_amd.SquareLattice(4)).directions[0]) == [0.0, 0.0]
+
+
+def test_each_local_quad_by_distance(mc_amd, R):
+    """EachLocalQuadByDistance{K} (lattice_iterators.jl:258-353): length, grouping and the
+    geometric meaning of every quadruple; K defaults to 1 + number of nearest neighbours"""
+    L = 4
+    l = mc_amd.SquareLattice(L)
+    it = mc_amd.EachLocalQuadByDistance(l)
+    assert it.K == 5 and it.ndirections() == (16, 5, 5)
+    assert len(it) == (16 * 5) ** 2  # (sum of targets per source)^2, lattice_iterators.jl:281
+    dirs = it.pairs_by_dir.directions
+    pos = [np.array([i + 1.0, j + 1.0]) for j in range(L) for i in range(L)]
+
+    def same(a, b):  # equal up to lattice vectors
+        d = (a - b) / L
+        return np.abs(d - np.round(d)).max() < 1e-9
+
+    count, last = 0, 0
+    for lin, s1, t1, s2, t2 in it:
+        assert lin >= last  # sorted by the linear index of (dir12, dir1, dir2)
+        last = lin
+        d12, d1, d2 = (lin - 1) % 16, ((lin - 1) // 16) % 5, (lin - 1) // 80
+        assert same(pos[s1 - 1] - pos[s2 - 1], dirs[d12])
+        assert same(pos[s1 - 1] - pos[t1 - 1], dirs[d1]) and same(pos[s2 - 1] - pos[t2 - 1], dirs[d2])
+        count += 1
+    assert count == len(it)
+    # first direction is on-site, the next four are the nearest neighbours
+    assert np.all(it.trg_of[:, 0] == np.arange(16))
+    assert sorted(np.linalg.norm(d) for d in dirs[1:5]) == [1.0] * 4
+    # the independent restatement in the oracle sees the same target table
+    _, table = R.square_pair_directions(L)
+    for s in range(16):
+        for k in range(5):
+            assert table[s, it.trg_of[s, k]] == k
+    with pytest.raises(ValueError):
+        mc_amd.EachLocalQuadByDistance(mc_amd.SquareLattice(2), K=5)  # a 2x2 torus has 4 directions

@@ -37,3 +37,43 @@ def test_correlations_match_reference_formulas(gpu, O, R, kind):
     for k in ("CDC", "SDCx", "SDCy", "SDCz", "Mx", "My", "Mz"):
         assert np.abs(res[k] - ref[k] / 6).max() < 1e-10, k
     mc.close()
+
+
+@pytest.mark.parametrize("kind", ["attractive", "repulsive"])
+def test_pairing_correlation(gpu, O, R, kind):
+    """pairing_correlation = pc_kernel over EachLocalQuadByDistance{5} (measurements.jl:199-214)"""
+    L = 4
+    model = (gpu.HubbardModelAttractive if kind == "attractive" else gpu.HubbardModelRepulsive)(L, 2)
+    mc = gpu.DQMC(model, beta=1.0, n_walkers=3, seed=47)
+    it = gpu.EachLocalQuadByDistance(model.l)
+    mc.set_local_targets(it)
+    mc.prepare()
+    mc.reset_accumulators()
+    ref = np.zeros((16, 5, 5))
+    for _ in range(2):
+        mc.update_until_measure()
+        mc.accumulate_pairing()
+        for w in range(3):
+            ref += R.pairing_correlation(mc.greens(w), L, kind == "attractive", 5)
+    out, cnt = mc.pairing()
+    assert cnt == 6 and out.shape == (16, 5, 5)
+    assert np.abs(out - ref / 6).max() < 1e-12
+    # the same sums through the host iterator in the reference's iteration order
+    G = R.full_greens(mc.greens(0))
+    lin_sum = np.zeros(16 * 25)
+    for lin, s1, t1, s2, t2 in it:
+        lin_sum[lin - 1] += R.pc_kernel(G, 16, s1 - 1, t1 - 1, s2 - 1, t2 - 1)
+    one = R.pairing_correlation(mc.greens(0), L, kind == "attractive", 5)
+    assert np.abs(lin_sum.reshape((16, 5, 5), order="F") / 16 - one).max() < 1e-12
+    mc.reset_accumulators()
+    mc.accumulate_pairing()
+    assert mc.pairing()[1] == 3
+    mc.close()
+
+
+def test_pairing_requires_tables(gpu):
+    mc = gpu.DQMC(gpu.HubbardModelAttractive(4, 2), beta=1.0, n_walkers=1)
+    mc.prepare()
+    with pytest.raises(RuntimeError):
+        mc.accumulate_pairing()
+    mc.close()

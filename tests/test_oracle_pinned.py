@@ -252,3 +252,43 @@ def test_correlation_goldens(O, R):
     assert np.abs(sdc - np.array(g["SDCx_mean"])).max() < g["atol"]
     # structure: on-site first, then the four symmetry-equivalent nearest neighbours
     assert cdc[0] > 1.4 and np.ptp(cdc[1:5]) < 0.02
+
+
+def test_pairing_kernel_against_ed(O, R):
+    """pc_kernel (measurements.jl:208-214, "verified against ED for each (src1, src2, trg1, trg2)"):
+    at U = 0 Wick's theorem is exact, so the kernel applied to the exact Green's function must equal
+    the four-point function <c_{s1,up} c_{t1,dn} c^dag_{t2,dn} c^dag_{s2,up}> taken in the Fock space
+    (test/ED/ED.jl conventions, 2x2 lattice); a spin-mixing hopping is added so that the second,
+    cross-spin product of the kernel is exercised as well"""
+    neighs = O.square_neighs(2)
+    rho, c, cd = R.ed_hubbard_greens(neighs, 4, 0.0, 1.0, 0.3, 1.0, return_state=True)
+    N = 4
+    G = np.array([[np.trace(rho @ c[a] @ cd[b]) for b in range(2 * N)] for a in range(2 * N)])
+    worst = 0.0
+    for s1 in range(N):
+        for t1 in range(N):
+            for s2 in range(N):
+                for t2 in range(N):
+                    worst = max(worst, abs(R.pc_kernel(G, N, s1, t1, s2, t2) - R.ed_pairing(rho, c, cd, N, s1, t1, s2, t2)))
+    assert worst < 1e-12
+    # quadratic Hamiltonian WITH spin mixing: both Wick contractions contribute
+    rng = np.random.default_rng(5)
+    h = rng.standard_normal((2 * N, 2 * N)); h = h + h.T
+    H = sum(h[a, b] * cd[a] @ c[b] for a in range(2 * N) for b in range(2 * N))
+    w, V = np.linalg.eigh(H)
+    rho = (V * np.exp(-0.7 * (w - w.min()))) @ V.T
+    rho /= np.trace(rho)
+    G = np.array([[np.trace(rho @ c[a] @ cd[b]) for b in range(2 * N)] for a in range(2 * N)])
+    assert np.abs(G[:N, N:]).max() > 1e-3
+    worst = max(abs(R.pc_kernel(G, N, s1, t1, s2, t2) - R.ed_pairing(rho, c, cd, N, s1, t1, s2, t2))
+                for s1 in range(N) for t1 in range(N) for s2 in range(N) for t2 in range(N))
+    assert worst < 1e-12
+
+
+def test_pairing_attractive_override_is_the_generic_kernel(O, R):
+    """HubbardModelAttractive.jl:243-245 = the generic kernel on blockdiag(G, G)"""
+    rng = np.random.default_rng(2)
+    Gb = rng.standard_normal((16, 16))
+    a = R.pairing_correlation([Gb], 4, True, 5)
+    g = R.pairing_correlation([Gb, Gb], 4, False, 5)
+    assert a.shape == (16, 5, 5) and np.abs(a - g).max() < 1e-13
