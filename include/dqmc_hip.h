@@ -189,6 +189,32 @@ int dqmc_pairing_size(dqmc_handle *h, size_t *n_doubles);
 int dqmc_get_pairing(dqmc_handle *h, double *host_out);
 int dqmc_export_pairing(dqmc_handle *h, void *device_out);
 
+/* ---- unequal-time Green's functions -------------------------------------------
+ * UnequalTimeStack and its users (src/flavors/DQMC/unequal_time_stack.jl), for all walkers of the
+ * handle at once; the sweep state (mc.s.greens, the DQMC stack, current_slice) is not disturbed.
+ * The stacks are rebuilt lazily after the HS field has changed (the role of mc.last_sweep, :164-169).
+ * Results stay on the device in three n x n x units buffers: `which` = 0 holds G(k,l) of
+ * dqmc_ut_greens / the GreensIterator, or G0l of the CombinedGreensIterator; 1 = Gl0; 2 = Gll. */
+/* build_stack(mc, mc.ut_stack) (:106-160) */
+int dqmc_ut_build_stack(dqmc_handle *h);
+/* stack inspection for tests (test/flavortests_DQMC.jl:75-96): which 0 forward, 1 backward, 2 inverse;
+ * idx 0-based slot; per walker nb*n*n (U, T) and nb*n (D) doubles */
+int dqmc_ut_get_stack(dqmc_handle *h, int32_t w, int32_t which, int32_t idx, double *U, double *D, double *T);
+/* calculate_greens(mc, slice1, slice2) (:288-303; full1 :447-530, full2 :534-605) with 0 <= slices <=
+ * slices; effective != 0 returns the stack's effective G, 0 applies _greens! (DQMC.jl:721-730) like
+ * greens(mc, k, l) (:260-287) */
+int dqmc_ut_greens(dqmc_handle *h, int32_t slice1, int32_t slice2, int32_t effective);
+int dqmc_ut_get(dqmc_handle *h, int32_t w, int32_t which, double *host_out);
+int dqmc_ut_export(dqmc_handle *h, int32_t which, void *device_out /* units*n*n doubles */);
+/* GreensIterator(mc, :, l, recalculate) (:644-715): begin computes G(l <- l); each next advances k by one
+ * and returns it in *k (-1 when exhausted); result in buffer 0 */
+int dqmc_greens_iterator_begin(dqmc_handle *h, int32_t l, int32_t recalculate);
+int dqmc_greens_iterator_next(dqmc_handle *h, int32_t *k);
+/* CombinedGreensIterator(mc, recalculate) (:746-883): needs current_slice == 1; each next returns
+ * l = 1..slices in *l (-1 when exhausted) with (G0l, Gl0, Gll) in buffers 0, 1, 2 */
+int dqmc_combined_iterator_begin(dqmc_handle *h, int32_t recalculate);
+int dqmc_combined_iterator_next(dqmc_handle *h, int32_t *l);
+
 /* ---- batched linalg primitives (unit parity with test/slice_matrices.jl) --
  * host in / host out, `batch` independent n x n problems, run on device_id.  */
 /* vmul! family (src/linalg/general.jl:7-56): C = op(A)*op(B); transa/transb 0|1 */

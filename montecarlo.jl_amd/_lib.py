@@ -88,6 +88,15 @@ SIGNATURES = {
     "dqmc_pairing_size": (C.c_int, [_H, C.POINTER(C.c_size_t)]),
     "dqmc_get_pairing": (C.c_int, [_H, _dp]),
     "dqmc_export_pairing": (C.c_int, [_H, C.c_void_p]),
+    "dqmc_ut_build_stack": (C.c_int, [_H]),
+    "dqmc_ut_get_stack": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_int32, _dp, _dp, _dp]),
+    "dqmc_ut_greens": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_int32]),
+    "dqmc_ut_get": (C.c_int, [_H, C.c_int32, C.c_int32, _dp]),
+    "dqmc_ut_export": (C.c_int, [_H, C.c_int32, C.c_void_p]),
+    "dqmc_greens_iterator_begin": (C.c_int, [_H, C.c_int32, C.c_int32]),
+    "dqmc_greens_iterator_next": (C.c_int, [_H, C.POINTER(C.c_int32)]),
+    "dqmc_combined_iterator_begin": (C.c_int, [_H, C.c_int32]),
+    "dqmc_combined_iterator_next": (C.c_int, [_H, C.POINTER(C.c_int32)]),
     "dqmc_vmul": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _dp, _dp, _dp]),
     "dqmc_udt_pivot": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _dp, _dp, _dp, _i64p, C.c_int32]),
     "dqmc_rdivp": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _dp, _dp, _i64p]),

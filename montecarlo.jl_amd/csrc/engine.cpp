@@ -20,6 +20,8 @@ using namespace dqmc;
 
 static thread_local std::string g_create_error;
 
+struct UTStack;  // unequal-time stack (unequal_time.inl)
+
 struct dqmc_handle {
     dqmc_params p{};
     int n = 0, nb = 1, N = 0, M = 0, s = 0, K = 0, W = 0, units = 0, kd = 32;
@@ -54,6 +56,8 @@ struct dqmc_handle {
     size_t corr_n = 0;
     int current_slice = 0, direction = 0;
     bool prepared = false;
+    long long conf_version = 0;     // bumped whenever the HS field changes (mc.last_sweep's role for the UT stack)
+    UTStack *ut = nullptr;
     std::string err;
     // timing
     bool timing = false;
@@ -481,6 +485,7 @@ static int sweep_spatial(dqmc_handle *h)
     const int l = h->current_slice;
     if (l < 1 || l > h->M) return fail(h, DQMC_ERR_STATE, "sweep_spatial: current_slice outside 1..slices");
     int8_t *cslice = h->conf + (long)(l - 1) * h->N;
+    h->conf_version++;
     for (int site0 = 0; site0 < h->N; site0 += h->kd) {
         const int ns = std::min(h->kd, h->N - site0);
         {
@@ -626,6 +631,7 @@ int dqmc_create(const dqmc_params *p, dqmc_handle **out)
     return DQMC_OK;
 }
 
+static void ut_free(dqmc_handle *h);
 int dqmc_destroy(dqmc_handle *h)
 {
     if (!h) return DQMC_OK;
@@ -637,6 +643,7 @@ int dqmc_destroy(dqmc_handle *h)
     for (double *u : h->uniforms)
         if (u) (void)hipFree(u);
     if (h->stream) (void)hipStreamDestroy(h->stream);
+    ut_free(h);
     delete h;
     return DQMC_OK;
 }
@@ -655,6 +662,7 @@ int dqmc_set_conf(dqmc_handle *h, int32_t w, const int8_t *conf)
         if (conf[i] != 1 && conf[i] != -1) return fail(h, DQMC_ERR_INVALID, "conf entries must be +1 or -1");
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(h->conf + (size_t)w * sz, conf, sz, hipMemcpyHostToDevice));
+    h->conf_version++;
     return DQMC_OK;
 }
 int dqmc_get_conf(dqmc_handle *h, int32_t w, int8_t *conf)
@@ -907,6 +915,7 @@ int dqmc_set_conf_bits(dqmc_handle *h, int32_t w, const uint64_t *chunks)
     hipError_t e3 = e2 == hipSuccess ? hipStreamSynchronize(h->stream) : e2;
     (void)hipFree(d);
     HIPCHK(e3);
+    h->conf_version++;
     return DQMC_OK;
 }
 
@@ -1098,6 +1107,8 @@ int dqmc_export_accumulators(dqmc_handle *h, void *device_out)
     HIPCHK(hipStreamSynchronize(h->stream));
     return DQMC_OK;
 }
+
+#include "unequal_time.inl"
 
 int dqmc_timing_enable(dqmc_handle *h, int32_t on)
 {

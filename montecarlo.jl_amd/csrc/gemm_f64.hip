@@ -23,18 +23,6 @@ constexpr int BM = 64, BN = 64, BK = 16;
 // one 32-lane half reads with ds_read_b64 on disjoint bank halves.
 constexpr int LS = 80;
 
-__device__ __forceinline__ double vs_get(const VecSrc &v, int unit, int nb, int i)
-{
-    if (v.mode == 1) return v.d[(long)unit * v.stride + i];
-    if (v.mode == 3) return 1.0 / v.d[(long)unit * v.stride + i];
-    if (v.mode == 2) {
-        const int w = unit / nb, b = unit - w * nb;
-        const int8_t c = v.conf[(long)w * v.conf_stride + i];
-        return c > 0 ? v.cpos[b] : v.cneg[b];
-    }
-    return 1.0;
-}
-
 // "direct" tile: the 64-long index (m or n) is contiguous in memory.
 //   element(c, k) = p[c + ld*k]; thread -> k = tid/16, c = (tid%16)*4 .. +3
 // "transposing" tile: k is contiguous in memory.

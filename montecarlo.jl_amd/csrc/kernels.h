@@ -14,7 +14,8 @@ namespace dqmc {
 // the HS field: exp(±lambda*conf[i,l]) takes only two values
 // (HubbardModelAttractive.jl:100-110, HubbardModelRepulsive.jl:113-126).
 struct VecSrc {
-    int mode;  // 0 = none (1.0), 1 = d[i], 2 = conf-derived, 3 = 1.0/d[i]
+    int mode;  // 0 = none (1.0), 1 = d[i], 2 = conf-derived, 3 = 1.0/d[i],
+               // 4 = min(1, d[i]) (vmin!), 5 = 1/max(1, d[i]) (vmaxinv!, general.jl:90-117)
     const double *d;
     long stride;          // per unit
     const int8_t *conf;   // conf + walker*conf_stride + i  (already offset to the slice)
@@ -24,6 +25,23 @@ struct VecSrc {
 static inline VecSrc vs_none() { VecSrc v = {}; v.mode = 0; return v; }
 static inline VecSrc vs_arr(const double *d, long stride) { VecSrc v = {}; v.mode = 1; v.d = d; v.stride = stride; return v; }
 static inline VecSrc vs_inv(const double *d, long stride) { VecSrc v = {}; v.mode = 3; v.d = d; v.stride = stride; return v; }
+static inline VecSrc vs_min1(const double *d, long stride) { VecSrc v = {}; v.mode = 4; v.d = d; v.stride = stride; return v; }
+static inline VecSrc vs_maxinv(const double *d, long stride) { VecSrc v = {}; v.mode = 5; v.d = d; v.stride = stride; return v; }
+#ifdef __HIPCC__
+__device__ __forceinline__ double vs_get(const VecSrc &v, int unit, int nb, int i)
+{
+    if (v.mode == 1) return v.d[(long)unit * v.stride + i];
+    if (v.mode == 3) return 1.0 / v.d[(long)unit * v.stride + i];
+    if (v.mode == 2) {
+        const int w = unit / nb, b = unit - w * nb;
+        const int8_t c = v.conf[(long)w * v.conf_stride + i];
+        return c > 0 ? v.cpos[b] : v.cneg[b];
+    }
+    if (v.mode == 4) return fmin(1.0, v.d[(long)unit * v.stride + i]);
+    if (v.mode == 5) return 1.0 / fmax(1.0, v.d[(long)unit * v.stride + i]);
+    return 1.0;
+}
+#endif
 
 struct MatRef {
     const double *p;
@@ -113,6 +131,14 @@ hipError_t launch_sweep_chunk(int n, int nb, int n_walkers, int model, double *G
 // small helpers
 hipError_t launch_set_identity(int n, int count, double *A, long stride, hipStream_t s);
 hipError_t launch_fill(double *p, size_t n, double v, hipStream_t s);
+// elementwise helpers of the unequal-time path: A = Diagonal(d) (copyto!(A, Diagonal(d))), A += B (rvadd!),
+// O = A - I (vsub!, general.jl:67-85), d = f(d) in place with f given by the VecSrc mode
+hipError_t launch_set_diag(int n, int nb, int units, double *A, long stride, VecSrc d, hipStream_t s);
+hipError_t launch_mat_add(double *A, const double *B, size_t count, hipStream_t s);
+hipError_t launch_sub_identity(int n, int units, double *O, const double *A, long stride, hipStream_t s);
+hipError_t launch_vec_map(int n, int nb, int units, double *dst, long stride, VecSrc src, hipStream_t s);
+hipError_t launch_scale_mat(int n, int nb, int units, double *O, const double *A, long stride, VecSrc row, VecSrc col,
+                            int row_first, hipStream_t s);
 // per walker max|A-B| over its nb blocks; pushes log10 into stats.propagation_error if > 1e-7
 hipError_t launch_prop_check(int n, int nb, int n_walkers, const double *A, const double *B,
                              long stride_unit, DevStats *stats, hipStream_t s);

@@ -285,6 +285,93 @@ hipError_t launch_set_identity(int n, int count, double *A, long stride, hipStre
     hipLaunchKernelGGL(set_identity_kernel, dim3(bx, count), dim3(256), 0, s, n, A, stride);
     return hipGetLastError();
 }
+__global__ void set_diag_kernel(int n, int nb, double *A, long stride, VecSrc d)
+{
+    const int unit = blockIdx.y;
+    double *a = A + (long)unit * stride;
+    const long nn = (long)n * n;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < nn; idx += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(idx % n), c = (int)(idx / n);
+        a[idx] = r == c ? vs_get(d, unit, nb, r) : 0.0;
+    }
+}
+hipError_t launch_set_diag(int n, int nb, int units, double *A, long stride, VecSrc d, hipStream_t s)
+{
+    const long nn = (long)n * n;
+    int bx = (int)((nn + 255) / 256);
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(set_diag_kernel, dim3(bx, units), dim3(256), 0, s, n, nb, A, stride, d);
+    return hipGetLastError();
+}
+__global__ void mat_add_kernel(double *__restrict__ A, const double *__restrict__ B, size_t count)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x)
+        A[i] += B[i];
+}
+hipError_t launch_mat_add(double *A, const double *B, size_t count, hipStream_t s)
+{
+    size_t b = (count + 255) / 256;
+    if (b > 4096) b = 4096;
+    if (b == 0) b = 1;
+    hipLaunchKernelGGL(mat_add_kernel, dim3((unsigned)b), dim3(256), 0, s, A, B, count);
+    return hipGetLastError();
+}
+__global__ void sub_identity_kernel(int n, double *__restrict__ O, const double *__restrict__ A, long stride)
+{
+    double *o = O + (long)blockIdx.y * stride;
+    const double *a = A + (long)blockIdx.y * stride;
+    const long nn = (long)n * n;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < nn; idx += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(idx % n), c = (int)(idx / n);
+        o[idx] = a[idx] - (r == c ? 1.0 : 0.0);
+    }
+}
+hipError_t launch_sub_identity(int n, int units, double *O, const double *A, long stride, hipStream_t s)
+{
+    const long nn = (long)n * n;
+    int bx = (int)((nn + 255) / 256);
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(sub_identity_kernel, dim3(bx, units), dim3(256), 0, s, n, O, A, stride);
+    return hipGetLastError();
+}
+// O = Diagonal(row) * A * Diagonal(col), the two scalings applied in the reference's order
+__global__ void scale_mat_kernel(int n, int nb, double *__restrict__ O, const double *__restrict__ A, long stride,
+                                 VecSrc row, VecSrc col, int row_first)
+{
+    const int unit = blockIdx.y;
+    double *o = O + (long)unit * stride;
+    const double *a = A + (long)unit * stride;
+    const long nn = (long)n * n;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < nn; idx += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(idx % n), c = (int)(idx / n);
+        const double rs = row.mode ? vs_get(row, unit, nb, r) : 1.0, cs = col.mode ? vs_get(col, unit, nb, c) : 1.0;
+        double v = a[idx];
+        if (row_first) { v *= rs; v *= cs; } else { v *= cs; v *= rs; }
+        o[idx] = v;
+    }
+}
+hipError_t launch_scale_mat(int n, int nb, int units, double *O, const double *A, long stride, VecSrc row, VecSrc col,
+                            int row_first, hipStream_t s)
+{
+    const long nn = (long)n * n;
+    int bx = (int)((nn + 255) / 256);
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(scale_mat_kernel, dim3(bx, units), dim3(256), 0, s, n, nb, O, A, stride, row, col, row_first);
+    return hipGetLastError();
+}
+__global__ void vec_map_kernel(int n, int nb, double *dst, long stride, VecSrc src)
+{
+    const int unit = blockIdx.x;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const double v = vs_get(src, unit, nb, i);  // src may alias dst: each element is read, then written
+        dst[(long)unit * stride + i] = v;
+    }
+}
+hipError_t launch_vec_map(int n, int nb, int units, double *dst, long stride, VecSrc src, hipStream_t s)
+{
+    hipLaunchKernelGGL(vec_map_kernel, dim3(units), dim3(256), 0, s, n, nb, dst, stride, src);
+    return hipGetLastError();
+}
 __global__ void fill_kernel(double *p, size_t n, double v)
 {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;

@@ -367,6 +367,58 @@ class DQMC:
         cnt = out[-1]
         return out[:-1].reshape((self._ndirs, self._K, self._K), order="F") / cnt, cnt
 
+    # ---- unequal-time Green's functions (src/flavors/DQMC/unequal_time_stack.jl)
+    def ut_build_stack(self):
+        """build_stack(mc, mc.ut_stack)"""
+        self._c(lib().dqmc_ut_build_stack(self._h))
+
+    def ut_stack(self, which, idx, walker=0):
+        """(U, D, T) blocks of slot idx (0-based) of the forward / backward / inverse stack"""
+        sel = {"forward": 0, "backward": 1, "inverse": 2}[which]
+        U = np.zeros(self.nb * self.N * self.N); T = np.zeros_like(U); D = np.zeros(self.nb * self.N)
+        self._c(lib().dqmc_ut_get_stack(self._h, walker, sel, idx, dptr(U), dptr(D), dptr(T)))
+        return self._blocks(U), [D[b * self.N:(b + 1) * self.N] for b in range(self.nb)], self._blocks(T)
+
+    def _ut_result(self, which, walker):
+        out = np.zeros(self.nb * self.N * self.N)
+        self._c(lib().dqmc_ut_get(self._h, walker, which, dptr(out)))
+        return self._blocks(out)
+
+    def calculate_greens_kl(self, slice1, slice2, walker=0):
+        """calculate_greens(mc, slice1, slice2): the effective G(slice1 <- slice2)"""
+        self._c(lib().dqmc_ut_greens(self._h, slice1, slice2, 1))
+        return self._ut_result(0, walker)
+
+    def greens_kl(self, slice1, slice2, walker=None):
+        """greens(mc, k, l) = <c_i(k dtau) c_j^dagger(l dtau)>; walker=None returns every walker"""
+        self._c(lib().dqmc_ut_greens(self._h, slice1, slice2, 0))
+        if walker is None:
+            return [self._ut_result(0, w) for w in range(self.n_walkers)]
+        return self._ut_result(0, walker)
+
+    def greens_iterator(self, l=0, recalculate=None, walker=0):
+        """GreensIterator(mc, :, l, recalculate): yields G(k <- l) for k = l..slices"""
+        recalculate = 4 * self.p.safe_mult if recalculate is None else recalculate
+        self._c(lib().dqmc_greens_iterator_begin(self._h, l, recalculate))
+        yield self._ut_result(0, walker)
+        k = C.c_int32()
+        while True:
+            self._c(lib().dqmc_greens_iterator_next(self._h, C.byref(k)))
+            if k.value < 0:
+                return
+            yield self._ut_result(0, walker)
+
+    def combined_greens_iterator(self, recalculate=None, walker=0):
+        """CombinedGreensIterator(mc, recalculate): yields (G0l, Gl0, Gll) for l = 1..slices"""
+        recalculate = 4 * self.p.safe_mult if recalculate is None else recalculate
+        self._c(lib().dqmc_combined_iterator_begin(self._h, recalculate))
+        l = C.c_int32()
+        while True:
+            self._c(lib().dqmc_combined_iterator_next(self._h, C.byref(l)))
+            if l.value < 0:
+                return
+            yield tuple(self._ut_result(i, walker) for i in range(3))
+
     # ---- instrumentation
     def timing_enable(self, on=True):
         self._c(lib().dqmc_timing_enable(self._h, int(on)))
