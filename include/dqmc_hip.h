@@ -215,6 +215,19 @@ int dqmc_greens_iterator_next(dqmc_handle *h, int32_t *k);
 int dqmc_combined_iterator_begin(dqmc_handle *h, int32_t recalculate);
 int dqmc_combined_iterator_next(dqmc_handle *h, int32_t *l);
 
+/* Susceptibilities on the device: apply!(::CombinedGreensIterator, ...) (measurements/generic.jl:226-243)
+ * for charge_density_susceptibility, spin_density_susceptibility(:x, :y, :z) and, when
+ * dqmc_set_local_targets has been called, pairing_susceptibility (measurements.jl:57-58,142-144,207;
+ * packed kernels :76-92,158-192,215-219; HubbardModelAttractive.jl:226-249): the sum over l = 1..slices
+ * of kernel(G00, G0l, Gl0, Gll), times delta_tau / n_sites as finish! does.  Needs current_slice == 1
+ * and dqmc_set_pair_directions.  Accumulator layout:
+ *   [cds n_dirs][sds_x n_dirs][sds_y n_dirs][sds_z n_dirs][ps n_dirs x K x K][samples]
+ * dqmc_reset_accumulators clears these sums too. */
+int dqmc_accumulate_susceptibilities(dqmc_handle *h, int32_t recalculate);
+int dqmc_susceptibilities_size(dqmc_handle *h, size_t *n_doubles);
+int dqmc_get_susceptibilities(dqmc_handle *h, double *host_out);
+int dqmc_export_susceptibilities(dqmc_handle *h, void *device_out);
+
 /* ---- batched linalg primitives (unit parity with test/slice_matrices.jl) --
  * host in / host out, `batch` independent n x n problems, run on device_id.  */
 /* vmul! family (src/linalg/general.jl:7-56): C = op(A)*op(B); transa/transb 0|1 */

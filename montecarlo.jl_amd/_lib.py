@@ -97,6 +97,10 @@ SIGNATURES = {
     "dqmc_greens_iterator_next": (C.c_int, [_H, C.POINTER(C.c_int32)]),
     "dqmc_combined_iterator_begin": (C.c_int, [_H, C.c_int32]),
     "dqmc_combined_iterator_next": (C.c_int, [_H, C.POINTER(C.c_int32)]),
+    "dqmc_accumulate_susceptibilities": (C.c_int, [_H, C.c_int32]),
+    "dqmc_susceptibilities_size": (C.c_int, [_H, C.POINTER(C.c_size_t)]),
+    "dqmc_get_susceptibilities": (C.c_int, [_H, _dp]),
+    "dqmc_export_susceptibilities": (C.c_int, [_H, C.c_void_p]),
     "dqmc_vmul": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _dp, _dp, _dp]),
     "dqmc_udt_pivot": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _dp, _dp, _dp, _i64p, C.c_int32]),
     "dqmc_rdivp": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _dp, _dp, _i64p]),

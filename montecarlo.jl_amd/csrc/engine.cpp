@@ -632,6 +632,7 @@ int dqmc_create(const dqmc_params *p, dqmc_handle **out)
 }
 
 static void ut_free(dqmc_handle *h);
+static int ut_reset_accumulators(dqmc_handle *h);
 int dqmc_destroy(dqmc_handle *h)
 {
     if (!h) return DQMC_OK;
@@ -1091,6 +1092,7 @@ int dqmc_reset_accumulators(dqmc_handle *h)
     HIPCHK(hipMemsetAsync(h->acc, 0, h->acc_n * sizeof(double), h->stream));
     if (h->corr_acc) HIPCHK(hipMemsetAsync(h->corr_acc, 0, h->corr_n * sizeof(double), h->stream));
     if (h->pc_acc) HIPCHK(hipMemsetAsync(h->pc_acc, 0, h->pc_n * sizeof(double), h->stream));
+    CHK(ut_reset_accumulators(h));
     return DQMC_OK;
 }
 int dqmc_get_accumulators(dqmc_handle *h, double *host_out)

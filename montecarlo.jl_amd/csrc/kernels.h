@@ -156,6 +156,14 @@ hipError_t launch_correlations(int n, int nb, int model, int n_walkers, const do
 hipError_t launch_pairing(int n, int nb, int n_walkers, const double *G, long stride_unit, const int *dir_ptr,
                           const int *pair_src, const int *pair_trg, int n_dirs, int K, const int *trg_of,
                           double *per_walker, double *acc, hipStream_t s);
+// susceptibilities: one time slice of the packed kernels added to per_walker [walkers][4*n_dirs (+ n_dirs*K*K)]
+// ([cds][sds_x][sds_y][sds_z][ps]); the reduce multiplies by delta_tau and adds the sample count
+hipError_t launch_sus_slice(int n, int nb, int model, int n_walkers, const double *G00, const double *G0l,
+                            const double *Gl0, const double *Gll, long stride_unit, const int *dir_ptr,
+                            const int *pair_src, const int *pair_trg, int n_dirs, int K, const int *trg_of,
+                            double *per_walker, long per_stride, hipStream_t s);
+hipError_t launch_sus_reduce(int n_walkers, long total, double factor, const double *per_walker, double *acc,
+                             hipStream_t s);
 // HS field <-> Julia BitArray chunks (compress / decompress, HubbardModel.jl:56-59)
 hipError_t launch_conf_pack(const int8_t *conf, size_t n_elem, unsigned long long *chunks, hipStream_t s);
 hipError_t launch_conf_unpack(const unsigned long long *chunks, size_t n_elem, int8_t *conf, hipStream_t s);

@@ -586,6 +586,114 @@ hipError_t launch_pairing(int n, int nb, int n_walkers, const double *G, long st
     return hipGetLastError();
 }
 
+// Time-displaced versions (packed Green's functions (G00, G0l, Gl0, Gll), measurements.jl:76-92,
+// 150-192, 215-219; attractive overrides HubbardModelAttractive.jl:226-246) for the susceptibilities
+// that apply!(::CombinedGreensIterator, ...) integrates over l (generic.jl:226-243).  Block-diagonal G:
+// every cross-spin element of the 2N x 2N formulas is 0.  Each launch ADDS the contribution of one
+// time slice to the per-walker sums (fixed order inside a workgroup: deterministic).
+__global__ __launch_bounds__(256) void sus_pairs_kernel(int n, int nb, int model, const double *__restrict__ G00,
+                                                       const double *__restrict__ G0l,
+                                                       const double *__restrict__ Gl0,
+                                                       const double *__restrict__ Gll, long stride_unit,
+                                                       const int *__restrict__ dir_ptr,
+                                                       const int *__restrict__ pair_src,
+                                                       const int *__restrict__ pair_trg, int n_dirs,
+                                                       double *__restrict__ per_walker, long per_stride)
+{
+    __shared__ double red[3][256];
+    const int d = blockIdx.x, w = blockIdx.y, tid = threadIdx.x;
+    const long u0 = (long)(w * nb) * stride_unit, u1 = nb == 2 ? u0 + stride_unit : u0;
+    double cdc = 0.0, sxy = 0.0, sz = 0.0;
+    for (int q = dir_ptr[d] + tid; q < dir_ptr[d + 1]; q += 256) {
+        const int i = pair_src[q], j = pair_trg[q];
+        const double l_up = 1.0 - Gll[u0 + i + (long)n * i], z_up = 1.0 - G00[u0 + j + (long)n * j];
+        const double x_up = G0l[u0 + j + (long)n * i] * Gl0[u0 + i + (long)n * j];
+        if (model == 0) {
+            cdc += 4.0 * l_up * z_up - 2.0 * x_up;
+            sxy += -2.0 * x_up;
+            sz += -2.0 * x_up;
+        } else {
+            const double l_dn = 1.0 - Gll[u1 + i + (long)n * i], z_dn = 1.0 - G00[u1 + j + (long)n * j];
+            const double x_dn = G0l[u1 + j + (long)n * i] * Gl0[u1 + i + (long)n * j];
+            cdc += l_up * z_up - x_up + l_up * z_dn + l_dn * z_up + l_dn * z_dn - x_dn;
+            // - G0l[j, i] Gl0[i+N, j+N] - G0l[j+N, i+N] Gl0[i, j]
+            sxy += -G0l[u0 + j + (long)n * i] * Gl0[u1 + i + (long)n * j] - G0l[u1 + j + (long)n * i] * Gl0[u0 + i + (long)n * j];
+            sz += l_up * z_up - x_up - l_up * z_dn - l_dn * z_up + l_dn * z_dn - x_dn;
+        }
+    }
+    red[0][tid] = cdc; red[1][tid] = sxy; red[2][tid] = sz;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off)
+            for (int q = 0; q < 3; ++q) red[q][tid] += red[q][tid + off];
+        __syncthreads();
+    }
+    if (tid < 4) {  // [cds][sds_x][sds_y][sds_z]; x and y coincide for block-diagonal G
+        const int src = tid == 0 ? 0 : (tid == 3 ? 2 : 1);
+        per_walker[(long)w * per_stride + (long)tid * n_dirs + d] += red[src][0] / (double)n;
+    }
+}
+// pc_kernel with packed Green's functions: Gl0[src1, src2] * Gl0[trg1+N, trg2+N] (- cross-spin term = 0)
+__global__ __launch_bounds__(256) void sus_pairing_kernel(int n, int nb, const double *__restrict__ Gl0,
+                                                         long stride_unit, const int *__restrict__ dir_ptr,
+                                                         const int *__restrict__ pair_src,
+                                                         const int *__restrict__ pair_trg, int n_dirs, int K,
+                                                         const int *__restrict__ trg_of,
+                                                         double *__restrict__ per_walker, long per_stride, long offset)
+{
+    __shared__ double red[256];
+    const int d = blockIdx.x, w = blockIdx.y, tid = threadIdx.x;
+    const double *G1 = Gl0 + (long)(w * nb) * stride_unit;
+    const double *G2 = nb == 2 ? G1 + stride_unit : G1;
+    for (int k2 = 0; k2 < K; ++k2)
+        for (int k1 = 0; k1 < K; ++k1) {
+            double s = 0.0;
+            for (int q = dir_ptr[d] + tid; q < dir_ptr[d + 1]; q += 256) {
+                const int s1 = pair_src[q], s2 = pair_trg[q];
+                const int t1 = trg_of[s1 + n * k1], t2 = trg_of[s2 + n * k2];
+                if (t1 >= 0 && t2 >= 0) s += G1[s1 + (long)n * s2] * G2[t1 + (long)n * t2];
+            }
+            red[tid] = s;
+            __syncthreads();
+            for (int off = 128; off > 0; off >>= 1) {
+                if (tid < off) red[tid] += red[tid + off];
+                __syncthreads();
+            }
+            if (tid == 0) per_walker[(long)w * per_stride + offset + d + (long)n_dirs * (k1 + K * k2)] += red[0] / (double)n;
+            __syncthreads();
+        }
+}
+// acc[e] += factor * sum_w per_walker[w][e]; acc[total] += n_walkers
+__global__ void sus_reduce_kernel(int n_walkers, long total, double factor, const double *__restrict__ per_walker,
+                                  double *__restrict__ acc)
+{
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        double s = 0.0;
+        for (int w = 0; w < n_walkers; ++w) s += per_walker[(long)w * total + e];
+        acc[e] += factor * s;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) acc[total] += (double)n_walkers;
+}
+hipError_t launch_sus_slice(int n, int nb, int model, int n_walkers, const double *G00, const double *G0l,
+                            const double *Gl0, const double *Gll, long stride_unit, const int *dir_ptr,
+                            const int *pair_src, const int *pair_trg, int n_dirs, int K, const int *trg_of,
+                            double *per_walker, long per_stride, hipStream_t s)
+{
+    hipLaunchKernelGGL(sus_pairs_kernel, dim3(n_dirs, n_walkers), dim3(256), 0, s, n, nb, model, G00, G0l, Gl0, Gll,
+                       stride_unit, dir_ptr, pair_src, pair_trg, n_dirs, per_walker, per_stride);
+    if (K > 0)
+        hipLaunchKernelGGL(sus_pairing_kernel, dim3(n_dirs, n_walkers), dim3(256), 0, s, n, nb, Gl0, stride_unit,
+                           dir_ptr, pair_src, pair_trg, n_dirs, K, trg_of, per_walker, per_stride, 4L * n_dirs);
+    return hipGetLastError();
+}
+hipError_t launch_sus_reduce(int n_walkers, long total, double factor, const double *per_walker, double *acc,
+                             hipStream_t s)
+{
+    hipLaunchKernelGGL(sus_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, n_walkers, total,
+                       factor, per_walker, acc);
+    return hipGetLastError();
+}
+
 // compress(mc, model, conf) = BitArray(conf .== 1) (HubbardModel.jl:56-59): Julia's BitArray keeps
 // element i (1-based, column-major) in bit (i-1) % 64 of chunk (i-1) / 64.  One wave packs one chunk.
 __global__ void conf_pack_kernel(const int8_t *__restrict__ conf, size_t n_elem, unsigned long long *__restrict__ chunks)

@@ -21,6 +21,9 @@ struct UTStack {
     double *Ul = nullptr, *Ur = nullptr, *Tl = nullptr, *Tr = nullptr, *Dl = nullptr, *Dr = nullptr;
     double *s1 = nullptr, *s2 = nullptr, *curr = nullptr;
     double *out[3] = {nullptr, nullptr, nullptr};  // results handed out: G(k,l) in out[0]; (G0l, Gl0, Gll)
+    double *g00 = nullptr;                            // greens!(mc) kept for the packed kernels
+    double *sus_per_walker = nullptr, *sus_acc = nullptr;
+    size_t sus_n = 0;                                 // doubles in sus_acc (last = sample count)
     int it_kind = 0;  // 0 none, 1 GreensIterator, 2 CombinedGreensIterator
     int it_pos = 0, it_l = 0, it_recalc = 0;
 };
@@ -29,6 +32,11 @@ static void ut_free(dqmc_handle *h)
 {
     delete h->ut;  // device buffers are owned by h->allocs
     h->ut = nullptr;
+}
+static int ut_reset_accumulators(dqmc_handle *h)
+{
+    if (h->ut && h->ut->sus_acc) HIPCHK(hipMemsetAsync(h->ut->sus_acc, 0, h->ut->sus_n * sizeof(double), h->stream));
+    return 0;
 }
 static double *ut_slot(dqmc_handle *h, double *base, int idx) { return base + (long)idx * h->units * h->nn; }
 static double *ut_dslot(dqmc_handle *h, double *base, int idx) { return base + (long)idx * h->units * h->n; }
@@ -47,6 +55,7 @@ static int ut_init(dqmc_handle *h)
     double **mats[] = {&u->U, &u->T, &u->greens, &u->tmp, &u->Ul, &u->Ur, &u->Tl, &u->Tr, &u->s1, &u->s2, &u->curr,
                        &u->out[0], &u->out[1], &u->out[2]};
     for (double **p : mats) CHK(dalloc(h, p, mat));
+    CHK(dalloc(h, &u->g00, mat));
     CHK(dalloc(h, &u->D, vec)); CHK(dalloc(h, &u->Dl, vec)); CHK(dalloc(h, &u->Dr, vec));
     u->inv_done.assign(u->nr, 0);
     // identities at the ends (unequal_time_stack.jl:90-96)
@@ -555,4 +564,70 @@ int dqmc_combined_iterator_next(dqmc_handle *h, int32_t *l)
     CHK(ut_cgi_next(h, &ll));
     *l = ll;
     return dqmc_synchronize(h);
+}
+
+// ---- susceptibilities: apply!(::CombinedGreensIterator, ...) (generic.jl:226-243) on the device -------------
+// charge_density_susceptibility, spin_density_susceptibility(:x/:y/:z), pairing_susceptibility
+// (measurements.jl:57-58,142-144,207): sum over l of kernel(G00, G0l, Gl0, Gll), finish! * delta_tau / N
+static int ut_sus_layout(dqmc_handle *h)
+{
+    UTStack *u = h->ut;
+    const size_t want = 4 * (size_t)h->n_dirs + (size_t)h->n_dirs * h->K_loc * h->K_loc + 1;
+    if (u->sus_n == want) return 0;
+    u->sus_n = want;
+    CHK(dalloc(h, &u->sus_per_walker, (size_t)h->W * (want - 1)));
+    CHK(dalloc(h, &u->sus_acc, want));
+    return 0;
+}
+int dqmc_accumulate_susceptibilities(dqmc_handle *h, int32_t recalculate)
+{
+    ENTER(h); NEED_UT(h);
+    if (!h->n_dirs) return fail(h, DQMC_ERR_STATE, "call dqmc_set_pair_directions first");
+    if (recalculate < 1) return fail(h, DQMC_ERR_INVALID, "recalculate must be positive");
+    UTStack *u = h->ut;
+    CHK(ut_sus_layout(h));
+    const long total = (long)u->sus_n - 1;
+    CHK(true_greens(h, h->greens));                                 // G00 = greens!(mc)
+    CHK(copy_mat(h, u->g00, h->tmp2));
+    HIPCHK(hipMemsetAsync(u->sus_per_walker, 0, sizeof(double) * h->W * total, h->stream));  // prepare!
+    CHK(ut_cgi_begin(h, recalculate));
+    for (;;) {
+        int l = -1;
+        CHK(ut_cgi_next(h, &l));
+        if (l < 0) break;
+        Timed t(h, DQMC_K_MISC);
+        HIPCHK(launch_sus_slice(h->n, h->nb, h->p.model_kind, h->W, u->g00, u->out[0], u->out[1], u->out[2], h->nn,
+                                h->dir_ptr, h->pair_src, h->pair_trg, h->n_dirs, h->K_loc, h->trg_of, u->sus_per_walker,
+                                total, h->stream));
+    }
+    {
+        Timed t(h, DQMC_K_MISC);
+        HIPCHK(launch_sus_reduce(h->W, total, h->p.delta_tau, u->sus_per_walker, u->sus_acc, h->stream));
+    }
+    return dqmc_synchronize(h);
+}
+int dqmc_susceptibilities_size(dqmc_handle *h, size_t *n)
+{
+    ENTER(h); NEED_UT(h);
+    if (!n) return DQMC_ERR_INVALID;
+    if (!h->n_dirs) return fail(h, DQMC_ERR_STATE, "call dqmc_set_pair_directions first");
+    CHK(ut_sus_layout(h));
+    *n = h->ut->sus_n;
+    return DQMC_OK;
+}
+int dqmc_get_susceptibilities(dqmc_handle *h, double *host_out)
+{
+    ENTER(h); NEED_UT(h);
+    if (!h->ut->sus_acc) return fail(h, DQMC_ERR_STATE, "nothing accumulated");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(host_out, h->ut->sus_acc, h->ut->sus_n * sizeof(double), hipMemcpyDeviceToHost));
+    return DQMC_OK;
+}
+int dqmc_export_susceptibilities(dqmc_handle *h, void *device_out)
+{
+    ENTER(h); NEED_UT(h);
+    if (!h->ut->sus_acc) return fail(h, DQMC_ERR_STATE, "nothing accumulated");
+    HIPCHK(hipMemcpyAsync(device_out, h->ut->sus_acc, h->ut->sus_n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return DQMC_OK;
 }

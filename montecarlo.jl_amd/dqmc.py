@@ -419,6 +419,27 @@ class DQMC:
                 return
             yield tuple(self._ut_result(i, walker) for i in range(3))
 
+    def accumulate_susceptibilities(self, recalculate=None):
+        """charge_density_/spin_density_/pairing_susceptibility: one pass of the CombinedGreensIterator
+        with the packed kernels summed on the device"""
+        recalculate = 4 * self.p.safe_mult if recalculate is None else recalculate
+        self._c(lib().dqmc_accumulate_susceptibilities(self._h, recalculate))
+
+    def susceptibilities(self):
+        """-> dict of means: CDS, SDSx, SDSy, SDSz per direction, PS[dir12, dir1, dir2] if local targets
+        are set, count"""
+        n = C.c_size_t()
+        self._c(lib().dqmc_susceptibilities_size(self._h, C.byref(n)))
+        out = np.zeros(n.value)
+        self._c(lib().dqmc_get_susceptibilities(self._h, dptr(out)))
+        nd, cnt = self._ndirs, out[-1]
+        res = {k: out[i * nd:(i + 1) * nd] / cnt for i, k in enumerate(["CDS", "SDSx", "SDSy", "SDSz"])}
+        K = getattr(self, "_K", 0)
+        if K:
+            res["PS"] = out[4 * nd:4 * nd + nd * K * K].reshape((nd, K, K), order="F") / cnt
+        res["count"] = cnt
+        return res
+
     # ---- instrumentation
     def timing_enable(self, on=True):
         self._c(lib().dqmc_timing_enable(self._h, int(on)))

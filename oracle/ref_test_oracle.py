@@ -280,3 +280,81 @@ def pairing_correlation(blocks, L, attractive, K):
                             else:
                                 out[d12, k1, k2] += pc_kernel(G, N, s1, t1, s2, t2)
     return out / N
+
+
+# --------------------------------------------------------------------------
+# packed-Green's-function kernels (G00, G0l, Gl0, Gll) in their generic 2N x 2N form
+# (measurements.jl:76-92, 158-192, 215-219) and the susceptibility sums of
+# apply!(::CombinedGreensIterator, ...) + finish!(..., delta_tau) (generic.jl:226-243, 283-290)
+def cdc_kernel_packed(pg, N, i, j):
+    G00, G0l, Gl0, Gll = pg
+    return ((1 - Gll[i, i]) * (1 - G00[j, j]) - G0l[j, i] * Gl0[i, j]
+            + (1 - Gll[i, i]) * (1 - G00[j + N, j + N]) - G0l[j + N, i] * Gl0[i, j + N]
+            + (1 - Gll[i + N, i + N]) * (1 - G00[j, j]) - G0l[j, i + N] * Gl0[i + N, j]
+            + (1 - Gll[i + N, i + N]) * (1 - G00[j + N, j + N]) - G0l[j + N, i + N] * Gl0[i + N, j + N])
+
+
+def sdc_x_kernel_packed(pg, N, i, j):
+    G00, G0l, Gl0, Gll = pg
+    return (Gll[i + N, i] * G00[j + N, j] - G0l[j + N, i] * Gl0[i + N, j]
+            + Gll[i + N, i] * G00[j, j + N] - G0l[j, i] * Gl0[i + N, j + N]
+            + Gll[i, i + N] * G00[j + N, j] - G0l[j + N, i + N] * Gl0[i, j]
+            + Gll[i, i + N] * G00[j, j + N] - G0l[j, i + N] * Gl0[i, j + N])
+
+
+def sdc_y_kernel_packed(pg, N, i, j):
+    G00, G0l, Gl0, Gll = pg
+    return (-Gll[i + N, i] * G00[j + N, j] + G0l[j + N, i] * Gl0[i + N, j]
+            + Gll[i + N, i] * G00[j, j + N] - G0l[j, i] * Gl0[i + N, j + N]
+            + Gll[i, i + N] * G00[j + N, j] - G0l[j + N, i + N] * Gl0[i, j]
+            - Gll[i, i + N] * G00[j, j + N] + G0l[j, i + N] * Gl0[i, j + N])
+
+
+def sdc_z_kernel_packed(pg, N, i, j):
+    G00, G0l, Gl0, Gll = pg
+    return ((1 - Gll[i, i]) * (1 - G00[j, j]) - G0l[j, i] * Gl0[i, j]
+            - (1 - Gll[i, i]) * (1 - G00[j + N, j + N]) + G0l[j + N, i] * Gl0[i, j + N]
+            - (1 - Gll[i + N, i + N]) * (1 - G00[j, j]) + G0l[j, i + N] * Gl0[i + N, j]
+            + (1 - Gll[i + N, i + N]) * (1 - G00[j + N, j + N]) - G0l[j + N, i + N] * Gl0[i + N, j + N])
+
+
+def pc_kernel_packed(pg, N, src1, trg1, src2, trg2):
+    Gl0 = pg[2]
+    return Gl0[src1, src2] * Gl0[trg1 + N, trg2 + N] - Gl0[src1, trg2 + N] * Gl0[trg1 + N, src2]
+
+
+def susceptibilities(g00_blocks, steps, L, attractive, K, delta_tau):
+    """steps: iterable over l of (G0l, Gl0, Gll), each a list of per-block matrices.  Returns what the
+    CombinedGreensIterator measurements push: CDS, SDSx/y/z per direction, PS[dir12, dir1, dir2]."""
+    N = L * L
+    dirs, table = square_pair_directions(L)
+    nd = len(dirs)
+    trg = [[[t for t in range(N) if table[s, t] == k] for k in range(K)] for s in range(N)]
+    out = {k: np.zeros(nd) for k in ("CDS", "SDSx", "SDSy", "SDSz")}
+    out["PS"] = np.zeros((nd, K, K))
+    G00 = full_greens(g00_blocks)
+    for g0l, gl0, gll in steps:
+        pg = (G00, full_greens(g0l), full_greens(gl0), full_greens(gll))
+        for i in range(N):
+            for j in range(N):
+                d = table[i, j]
+                if attractive:  # HubbardModelAttractive.jl:226-241
+                    x = pg[1][j, i] * pg[2][i, j]
+                    out["CDS"][d] += 4 * (1 - pg[3][i, i]) * (1 - pg[0][j, j]) - 2 * x
+                    out["SDSx"][d] += -2 * x; out["SDSy"][d] += -2 * x; out["SDSz"][d] += -2 * x
+                else:
+                    out["CDS"][d] += cdc_kernel_packed(pg, N, i, j)
+                    out["SDSx"][d] += sdc_x_kernel_packed(pg, N, i, j)
+                    out["SDSy"][d] += sdc_y_kernel_packed(pg, N, i, j)
+                    out["SDSz"][d] += sdc_z_kernel_packed(pg, N, i, j)
+                for k1 in range(K):
+                    for t1 in trg[i][k1]:
+                        for k2 in range(K):
+                            for t2 in trg[j][k2]:
+                                if attractive:  # HubbardModelAttractive.jl:246-248
+                                    out["PS"][d, k1, k2] += pg[2][i, j] * pg[2][t1, t2]
+                                else:
+                                    out["PS"][d, k1, k2] += pc_kernel_packed(pg, N, i, t1, j, t2)
+    for k in out:
+        out[k] = out[k] * delta_tau / N
+    return out

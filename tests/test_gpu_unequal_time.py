@@ -154,3 +154,34 @@ def test_unequal_time_config2_size(gpu):
     for k in (1, 15, 39):
         assert np.abs(mc.greens_kl(k, 0, 0)[0] + mc.greens_kl(k, M, 0)[0]).max() < 1e-11
     mc.close()
+
+
+@pytest.mark.parametrize("kind", ["attractive", "repulsive"])
+def test_susceptibilities(gpu, O, R, UT, kind):
+    """charge_density_/spin_density_/pairing_susceptibility summed on the device against the oracle's
+    CombinedGreensIterator + the generic packed kernels (generic.jl:226-243)"""
+    mc, oracles = _pair(gpu, O, kind, walkers=2)
+    L, s = 4, mc.p.safe_mult
+    it = gpu.EachLocalQuadByDistance(mc.model.l)
+    mc.set_local_targets(it)
+    mc.reset_accumulators()
+    mc.accumulate_susceptibilities(recalculate=s)
+    res = mc.susceptibilities()
+    assert res["count"] == 2 and res["PS"].shape == (16, 5, 5)
+    ref = None
+    for o in oracles:
+        uts = [UT.UnequalTimeOracle(o, b) for b in range(o.nb)]
+        its = [u.combined_greens_iterator(o.greens_eff()[b], s) for b, u in enumerate(uts)]
+        steps = [tuple([blk[q] for blk in per_block] for q in range(3)) for per_block in zip(*its)]
+        r = R.susceptibilities(o.greens(), steps, L, kind == "attractive", 5, o.delta_tau)
+        ref = r if ref is None else {k: ref[k] + r[k] for k in r}
+    for k in ("CDS", "SDSx", "SDSy", "SDSz", "PS"):
+        assert np.abs(res[k] - ref[k] / 2).max() < 1e-10 * max(1.0, np.abs(ref[k]).max()), k
+    # a second sample adds up; reset clears
+    mc.accumulate_susceptibilities(recalculate=s)
+    assert mc.susceptibilities()["count"] == 4
+    assert np.abs(mc.susceptibilities()["CDS"] - res["CDS"]).max() < 1e-12
+    mc.reset_accumulators()
+    mc.accumulate_susceptibilities()
+    assert mc.susceptibilities()["count"] == 2
+    mc.close()

@@ -111,3 +111,61 @@ def test_unequal_time_reference_setup(O, UT):
             assert np.abs(gl0 - Gk0[i + 1]).max() < tol
             assert np.abs(g0l - G0k[i + 1]).max() < tol
             assert np.abs(gll - Gkk[i + 1]).max() < tol
+
+
+def test_time_displaced_conventions_against_ed(O, R, UT):
+    """At U = 0 (lambda = 0: the slice matrices do not depend on the HS field) everything is exact and
+    Wick's theorem holds, so exact diagonalisation pins
+      * the sign / ordering conventions of G(l,0) = <c_i(tau) c_j^dag(0)> and G(0,l) = -<c_j^dag(tau) c_i(0)>
+        (unequal_time_stack.jl:262-265, full2's rmul!(-1)), up to the Trotter-free hopping (exact here
+        because [T, V] = 0 when V = 0),
+      * the packed kernels cdc / sdc_z / sdc_x / pc (measurements.jl:76-92,158-192,215-219) against the
+        imaginary-time correlators <A(tau) B(0)> = tr(rho e^{tau H} A e^{-tau H} B)."""
+    L, N, beta, dtau = 2, 4, 1.0, 0.1
+    mc = O.OracleDQMC(L, "repulsive", beta=beta, delta_tau=dtau, safe_mult=5, U=0.0)
+    mc.set_conf(O.random_conf(4, N, mc.slices)); mc.seed(4)
+    mc.prepare()
+    ut = [UT.UnequalTimeOracle(mc, b) for b in range(2)]
+    neighs = O.square_neighs(L)
+    rho, c, cd = R.ed_hubbard_greens(neighs, N, 0.0, 1.0, 0.0, beta, return_state=True)
+    # rebuild H to evolve operators: H = sum_sigma sum_<src,trg> -t c^dag_trg c_src
+    H = np.zeros_like(rho)
+    for s_ in range(2):
+        for src in range(N):
+            for trg in neighs[:, src] - 1:
+                H -= cd[N * s_ + trg] @ c[N * s_ + src]
+    w, V = np.linalg.eigh(H)
+
+    def heis(A, tau):  # e^{tau H} A e^{-tau H}
+        return (V * np.exp(tau * w)) @ V.T @ A @ (V * np.exp(-tau * w)) @ V.T
+
+    G00 = R.full_greens([ut[b].greens(0, 0) for b in range(2)])
+    for l in (1, 3, 7, 10):
+        tau = l * dtau
+        Gl0 = R.full_greens([ut[b].greens(l, 0) for b in range(2)])
+        G0l = R.full_greens([ut[b].greens(0, l) for b in range(2)])
+        Gll = R.full_greens([ut[b].greens(l, l) for b in range(2)])
+        for a_ in range(2 * N):
+            for b_ in range(2 * N):
+                assert abs(Gl0[a_, b_] - np.trace(rho @ heis(c[a_], tau) @ cd[b_])) < 1e-10
+                assert abs(G0l[a_, b_] + np.trace(rho @ heis(cd[b_], tau) @ c[a_])) < 1e-10
+        pg = (G00, G0l, Gl0, Gll)
+        n_op = [cd[a_] @ c[a_] for a_ in range(2 * N)]
+        for i in range(N):
+            for j in range(N):
+                ni, nj = n_op[i] + n_op[i + N], n_op[j] + n_op[j + N]
+                assert abs(R.cdc_kernel_packed(pg, N, i, j) - np.trace(rho @ heis(ni, tau) @ nj)) < 1e-10
+                szi, szj = n_op[i] - n_op[i + N], n_op[j] - n_op[j + N]
+                assert abs(R.sdc_z_kernel_packed(pg, N, i, j) - np.trace(rho @ heis(szi, tau) @ szj)) < 1e-10
+                sxi = cd[i] @ c[i + N] + cd[i + N] @ c[i]
+                sxj = cd[j] @ c[j + N] + cd[j + N] @ c[j]
+                assert abs(R.sdc_x_kernel_packed(pg, N, i, j) - np.trace(rho @ heis(sxi, tau) @ sxj)) < 1e-10
+                syi = cd[i] @ c[i + N] - cd[i + N] @ c[i]      # -i * S_y: the reference skips the factor (measurements.jl:104-106)
+                syj = cd[j] @ c[j + N] - cd[j + N] @ c[j]
+                assert abs(R.sdc_y_kernel_packed(pg, N, i, j) + np.trace(rho @ heis(syi, tau) @ syj)) < 1e-10
+        for s1 in range(N):
+            for t1 in range(N):
+                for s2 in range(N):
+                    for t2 in range(N):
+                        ed = np.trace(rho @ heis(c[s1] @ c[N + t1], tau) @ cd[N + t2] @ cd[s2])
+                        assert abs(R.pc_kernel_packed(pg, N, s1, t1, s2, t2) - ed) < 1e-10
