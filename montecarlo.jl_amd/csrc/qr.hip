@@ -500,6 +500,18 @@ __device__ __forceinline__ void qc_put(qc_word *slot, double v, unsigned tag_lo,
     __hip_atomic_store(slot + 1, (bits >> 32) | ((unsigned long long)tag_hi << 32), __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
 }
+// same payload with workgroup-scope stores: they stay in the XCD's L2 (MI355X_MICROARCH.md, visibility
+// table: plain / sc0 stores KEEP the line, sc1 stores DROP it and every reader pays the cross-XCD
+// rate).  Only other CUs of the SAME XCD can see them, so this form is used only after the eight
+// workgroups of a matrix have verified at run time that they share one XCD (see the kernel).
+__device__ __forceinline__ void qc_put_local(qc_word *slot, double v, unsigned tag_lo, unsigned tag_hi)
+{
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+    __hip_atomic_store(slot, (bits & 0xffffffffull) | ((unsigned long long)tag_lo << 32), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_store(slot + 1, (bits >> 32) | ((unsigned long long)tag_hi << 32), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 // spins until both halves carry their tags (tag_hi is compared under mask_hi); false on timeout
 __device__ __forceinline__ bool qc_get(const qc_word *slot, unsigned tag_lo, unsigned tag_hi, unsigned mask_hi,
                                        double &v, unsigned &hi_word)
@@ -560,7 +572,7 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v)
 __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double *__restrict__ Aall, long strideA,
                                                      double *__restrict__ tauall, int *__restrict__ pivall,
                                                      double *mailbox, unsigned long long *flags,
-                                                     unsigned long long epoch, int *errflag)
+                                                     unsigned long long epoch, int *errflag, int force_sc1)
 {
     __shared__ __attribute__((aligned(16))) double colbuf[256];   // my best column / the winning column
     __shared__ __attribute__((aligned(16))) double vperm[8 * QT_VS];
@@ -571,6 +583,7 @@ __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double
     __shared__ int wc_pos[4], wc_col[4];
     __shared__ int pos[256], colat[256];
     __shared__ int s_abort;
+    __shared__ int xcc_seen[QC_PARTS];
 
     const int bid = blockIdx.x, xcd = bid & 7, seq = bid >> 3;
     const int unit = (seq / QC_PARTS) * 8 + xcd, part = seq % QC_PARTS;
@@ -597,6 +610,27 @@ __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double
     colat[tid] = tid;
     if (tid == 0) s_abort = 0;
     __syncthreads();
+
+    // ---- placement check (once per launch): HIP promises nothing about workgroup -> XCD placement, so
+    // the eight parts exchange their XCC ids through agent-scope (sc1) packets and use the L2-resident
+    // store form only if all eight sit on one XCD; otherwise every packet is written through (sc1)
+    {
+        const unsigned tag0 = (unsigned)(epoch * 1024ull);   // step tags start at epoch*1024 + 1
+        const unsigned my_xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 0xfu;  // HW_REG_XCC_ID[3:0]
+        qc_word *pre = mb_unit + (long)(1 * QC_PARTS) * QC_MB * 2;  // parity-1 slots are first used at step 1
+        if (tid == 0) qc_put(pre + ((long)part * QC_MB + 256) * 2, (double)my_xcc, tag0, tag0);
+        if (tid < QC_PARTS) {
+            double v = -1.0;
+            unsigned hw;
+            if (!qc_get(pre + ((long)tid * QC_MB + 256) * 2, tag0, tag0, 0xffffffffu, v, hw)) s_abort = 1;
+            xcc_seen[tid] = (int)v;
+        }
+        __syncthreads();
+    }
+    bool same_xcd = true;
+#pragma unroll
+    for (int q = 1; q < QC_PARTS; ++q) same_xcd = same_xcd && xcc_seen[q] == xcc_seen[0];
+    if (force_sc1) same_xcd = false;
 
     for (int j = 0; j < n; ++j) {
         const int par = j & 1;
@@ -627,10 +661,16 @@ __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double
         // ---- publish: raw column + header as tagged packets; nothing to wait for
         {
             qc_word *mb = mb_unit + (long)(par * QC_PARTS + part) * QC_MB * 2;
-            qc_put(mb + 2 * tid, lbc >= 0 ? colbuf[tid] : 0.0, tag, tag);
+            const double pv = lbc >= 0 ? colbuf[tid] : 0.0;
             // header: norm in the payload, {position, column id} ride in the low half of the second tag
-            if (tid == 0)
-                qc_put(mb + 2 * 256, lbn, tag, (tag << 16) | ((unsigned)(lbp & 0xff) << 8) | (unsigned)(lbc & 0xff));
+            const unsigned htag = (tag << 16) | ((unsigned)(lbp & 0xff) << 8) | (unsigned)(lbc & 0xff);
+            if (same_xcd) {
+                qc_put_local(mb + 2 * tid, pv, tag, tag);
+                if (tid == 0) qc_put_local(mb + 2 * 256, lbn, tag, htag);
+            } else {
+                qc_put(mb + 2 * tid, pv, tag, tag);
+                if (tid == 0) qc_put(mb + 2 * 256, lbn, tag, htag);
+            }
         }
         // ---- collect: 8 lanes poll the 8 headers
         if (tid < QC_PARTS) {
@@ -734,8 +774,9 @@ hipError_t launch_qr_pivot(int n, int n_units, double *A, long strideA, double *
         const int blocks = groups * 8 * QC_PARTS;
         if (blocks <= ws->max_blocks) {
             ws->epoch += 1;
+            static const int force_sc1 = getenv("DQMC_QR_SC1") != nullptr;  // write-through packets regardless of placement
             hipLaunchKernelGGL(qr_coop_kernel, dim3(blocks), dim3(256), 0, s, n, n_units, A, strideA, tau, pivot,
-                               ws->mailbox, ws->flags, ws->epoch, ws->errflag);
+                               ws->mailbox, ws->flags, ws->epoch, ws->errflag, force_sc1);
             return hipGetLastError();
         }
     }
