@@ -577,10 +577,8 @@ __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double
     __shared__ __attribute__((aligned(16))) double colbuf[256];   // my best column / the winning column
     __shared__ __attribute__((aligned(16))) double vperm[8 * QT_VS];
     __shared__ double dummy[256];
-    __shared__ double hdr_norm[QC_PARTS];
-    __shared__ int hdr_pos[QC_PARTS], hdr_col[QC_PARTS];
-    __shared__ double wc_norm[4];
-    __shared__ int wc_pos[4], wc_col[4];
+    __shared__ __attribute__((aligned(16))) double wc[4][2];   // per wave: {norm, bits(pos | col << 32)}
+    __shared__ __attribute__((aligned(16))) double win[4];     // the step's pivot: {norm, bits(pos | col << 32), part, -}
     __shared__ int pos[256], colat[256];
     __shared__ int s_abort;
     __shared__ int xcc_seen[QC_PARTS];
@@ -617,12 +615,12 @@ __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double
     {
         const unsigned tag0 = (unsigned)(epoch * 1024ull);   // step tags start at epoch*1024 + 1
         const unsigned my_xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 0xfu;  // HW_REG_XCC_ID[3:0]
-        qc_word *pre = mb_unit + (long)(1 * QC_PARTS) * QC_MB * 2;  // parity-1 slots are first used at step 1
-        if (tid == 0) qc_put(pre + ((long)part * QC_MB + 256) * 2, (double)my_xcc, tag0, tag0);
+        qc_word *pre = mb_unit;  // packet 260 of the parity-0 slots is used by nothing else
+        if (tid == 0) qc_put(pre + ((long)part * QC_MB + 260) * 2, (double)my_xcc, tag0, tag0);
         if (tid < QC_PARTS) {
             double v = -1.0;
             unsigned hw;
-            if (!qc_get(pre + ((long)tid * QC_MB + 256) * 2, tag0, tag0, 0xffffffffu, v, hw)) s_abort = 1;
+            if (!qc_get(pre + ((long)tid * QC_MB + 260) * 2, tag0, tag0, 0xffffffffu, v, hw)) s_abort = 1;
             xcc_seen[tid] = (int)v;
         }
         __syncthreads();
@@ -643,14 +641,21 @@ __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double
             const unsigned bp = wave_min_u32<8>((live && nrm == bn) ? mp : 0xffffffffu);
             int bc = -1;
             if (bn >= 0.0) bc = __builtin_amdgcn_readlane(c, __ffsll((long long)__ballot(live && mp == bp)) - 1);
-            if (lane == 0) { wc_norm[w] = bn; wc_pos[w] = (int)(bp & 0x7fffffffu); wc_col[w] = bc; }
+            if (lane == 0) {
+                wc[w][0] = bn;
+                wc[w][1] = __longlong_as_double((long long)(bp & 0x7fffffffu) | ((long long)(unsigned)bc << 32));
+            }
         }
         __syncthreads();
-        double lbn = wc_norm[0];
-        int lbp = wc_pos[0], lbc = wc_col[0];
+        double lbn = -1.0;
+        int lbp = 0x7fffffff, lbc = -1;
 #pragma unroll
-        for (int q = 1; q < 4; ++q)
-            if (wc_norm[q] > lbn || (wc_norm[q] == lbn && wc_pos[q] < lbp)) { lbn = wc_norm[q]; lbp = wc_pos[q]; lbc = wc_col[q]; }
+        for (int q = 0; q < 4; ++q) {  // one 16-byte LDS read per wave candidate
+            const double2 cq = *reinterpret_cast<const double2 *>(wc[q]);
+            const long long pc = __double_as_longlong(cq.y);
+            const int qp = (int)(pc & 0x7fffffff), qc = (int)(pc >> 32);
+            if (cq.x > lbn || (cq.x == lbn && qp < lbp)) { lbn = cq.x; lbp = qp; lbc = qc; }
+        }
         // ---- its owner lanes put the column into LDS (wave-uniform branch, dummy sink for other lanes)
         if (lbc >= 0 && w == ((lbc >> 3) >> 3)) {
             double *dst = (cg == ((lbc >> 3) & 7)) ? colbuf : dummy;
@@ -662,35 +667,51 @@ __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double
         {
             qc_word *mb = mb_unit + (long)(par * QC_PARTS + part) * QC_MB * 2;
             const double pv = lbc >= 0 ? colbuf[tid] : 0.0;
-            // header: norm in the payload, {position, column id} ride in the low half of the second tag
-            const unsigned htag = (tag << 16) | ((unsigned)(lbp & 0xff) << 8) | (unsigned)(lbc & 0xff);
+            // header: packet 256 carries the norm, packet 258 {position, column id}; every word has the full tag
+            const double meta = __longlong_as_double((long long)(unsigned)lbp | ((long long)(unsigned)lbc << 32));
             if (same_xcd) {
                 qc_put_local(mb + 2 * tid, pv, tag, tag);
-                if (tid == 0) qc_put_local(mb + 2 * 256, lbn, tag, htag);
+                if (tid == 0) { qc_put_local(mb + 2 * 256, lbn, tag, tag); qc_put_local(mb + 2 * 258, meta, tag, tag); }
             } else {
                 qc_put(mb + 2 * tid, pv, tag, tag);
-                if (tid == 0) qc_put(mb + 2 * 256, lbn, tag, htag);
+                if (tid == 0) { qc_put(mb + 2 * 256, lbn, tag, tag); qc_put(mb + 2 * 258, meta, tag, tag); }
             }
         }
-        // ---- collect: 8 lanes poll the 8 headers
-        if (tid < QC_PARTS) {
-            double hn = 0.0;
-            unsigned hw = 0;
-            const qc_word *mb = mb_unit + (long)(par * QC_PARTS + tid) * QC_MB * 2;
-            if (!qc_get(mb + 2 * 256, tag, tag << 16, 0xffff0000u, hn, hw)) s_abort = 1;
-            hdr_norm[tid] = hn;
-            hdr_pos[tid] = (int)((hw >> 8) & 0xff);
-            hdr_col[tid] = hn < 0.0 ? -1 : (int)(hw & 0xff);  // norm -1: that workgroup has no live column
+        // ---- collect: 16 lanes of wave 0 poll the 8 headers (lane l: packet 256 + 2 (l & 1) of part l >> 1) and
+        // pick the step's pivot: largest norm, then smallest position (UDT.jl:151-168); only the result
+        // goes through LDS
+        if (w == 0) {
+            double hv = -1.0;
+            if (lane < 2 * QC_PARTS) {
+                unsigned hw;
+                const qc_word *mb = mb_unit + (long)(par * QC_PARTS + (lane >> 1)) * QC_MB * 2;
+                if (!qc_get(mb + 2 * (256 + 2 * (lane & 1)), tag, tag, 0xffffffffu, hv, hw)) s_abort = 1;
+            }
+            double bestn = -1.0;
+            int bestp = 0x7fffffff, bestc = -1, bestq = 0;
+#pragma unroll
+            for (int q = 0; q < QC_PARTS; ++q) {  // wave-uniform (SGPR) compares
+                const double qn = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(hv), 2 * q),
+                                                   __builtin_amdgcn_readlane(__double2loint(hv), 2 * q));
+                const int qp = __builtin_amdgcn_readlane(__double2loint(hv), 2 * q + 1);
+                const int qc = __builtin_amdgcn_readlane(__double2hiint(hv), 2 * q + 1);
+                if (qn >= 0.0 && (qn > bestn || (qn == bestn && qp < bestp))) { bestn = qn; bestp = qp; bestc = qc; bestq = q; }
+            }
+            if (lane == 0) {
+                win[0] = bestn;
+                win[1] = __longlong_as_double((long long)bestp | ((long long)(unsigned)bestc << 32));
+                win[2] = (double)bestq;
+            }
         }
         __syncthreads();
         if (s_abort) break;
-        double maxval = hdr_norm[0];
-        int jm = hdr_pos[0], cm = hdr_col[0], wpart = 0;
-#pragma unroll
-        for (int q = 1; q < QC_PARTS; ++q)
-            if (hdr_norm[q] > maxval || (hdr_norm[q] == maxval && hdr_pos[q] < jm)) {
-                maxval = hdr_norm[q]; jm = hdr_pos[q]; cm = hdr_col[q]; wpart = q;
-            }
+        double maxval;
+        int jm, cm, wpart;
+        {
+            const double2 w01 = *reinterpret_cast<const double2 *>(win);
+            const long long pc = __double_as_longlong(w01.y);
+            maxval = w01.x; jm = (int)(pc & 0x7fffffff); cm = (int)(pc >> 32); wpart = (int)win[2];
+        }
         if (cm < 0) { cm = colat[j]; jm = j; maxval = 0.0; wpart = cm & 7; }  // nothing live: cannot happen for j < n
         // ---- the winning column (tagged packets), reflector (UDT.jl:133-148), output column j
         double cv = 0.0;

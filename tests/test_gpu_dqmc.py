@@ -168,3 +168,19 @@ def test_ed_known_answer_on_gpu(gpu):
         a = mc.analysis(0)
         assert a.prop_local == 250 * 20 * 4 and a.propagation_error.count == 0
         mc.close()
+
+
+def test_repeated_udt_launches_are_bit_reproducible(gpu):
+    """The cooperative QR tags its mailbox packets with a per-handle launch counter; drive one handle
+    through several hundred launches (calculate_greens(mc, slice) = ~7 UDTs each, n = 16 and n = 64) and
+    require bit-identical Green's functions every time: the pivot decisions may not depend on timing
+    or on the launch counter (a 16-bit tag alias at launch 128 once did)."""
+    for L, reps in ((4, 90), (8, 40)):
+        mc = gpu.DQMC(gpu.HubbardModelRepulsive(L, 2), beta=1.0, safe_mult=5, n_walkers=3, seed=9)
+        mc.prepare()
+        first = [mc.calculate_greens(3, w) for w in range(3)]
+        for _ in range(reps):
+            for w in (0, 2):
+                g = mc.calculate_greens(3, w)
+                assert all(np.array_equal(g[b], first[w][b]) for b in range(2))
+        mc.close()
