@@ -122,15 +122,23 @@ __global__ __launch_bounds__(MAXT) void sweep_chunk_kernel(int n, int nb, int mo
         // ---- group start: bring the group's rows/columns up to date with all slots of the chunk
         {
             const int cnt0 = __builtin_amdgcn_readfirstlane(cnt);
-            constexpr int HB = 16;  // history slots in flight: L2 latency is paid once per batch
-            for (int mb = 0; mb < cnt0; mb += HB) {
-                double hu[HB], hv[HB];
+            constexpr int HB = 8;  // slots per batch; the next batch is in flight while this one is consumed
+            // padding lanes (t >= n) read row n-1 and slots past the end re-read slot cnt0-1: the loads carry
+            // no predicates; only the arithmetic of the last, partial batch sits behind wave-uniform branches
+            const double *__restrict__ hU = Uo + (active ? t : n - 1);
+            const double *__restrict__ hV = VTo + (active ? t : n - 1);
+            double hu[HB], hv[HB], hun[HB], hvn[HB];
+            auto load_batch = [&](int m0, double (&au)[HB], double (&av)[HB]) {
 #pragma unroll
                 for (int k = 0; k < HB; ++k) {
-                    const bool ok = active && mb + k < cnt0;
-                    hu[k] = ok ? Uo[t + (long)n * (mb + k)] : 0.0;
-                    hv[k] = ok ? VTo[t + (long)n * (mb + k)] : 0.0;
+                    const int m = min(m0 + k, cnt0 - 1);
+                    au[k] = hU[(long)n * m];
+                    av[k] = hV[(long)n * m];
                 }
+            };
+            if (cnt0 > 0) load_batch(0, hu, hv);
+            for (int mb = 0; mb < cnt0; mb += HB) {
+                if (mb + HB < cnt0) load_batch(mb + HB, hun, hvn);
 #pragma unroll
                 for (int k = 0; k < HB; ++k) {
                     if (mb + k < cnt0) {
@@ -142,6 +150,8 @@ __global__ __launch_bounds__(MAXT) void sweep_chunk_kernel(int n, int nb, int mo
                         }
                     }
                 }
+#pragma unroll
+                for (int k = 0; k < HB; ++k) { hu[k] = hun[k]; hv[k] = hvn[k]; }
             }
         }
 #pragma unroll
