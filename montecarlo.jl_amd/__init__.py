@@ -14,6 +14,6 @@ from .models import (HubbardModel, HubbardModelAttractive, HubbardModelRepulsive
                      rand_conf)
 from .sharding import reduce_accumulators, walker_range, walker_seeds  # noqa: F401
 from .dqmc import (DQMC, DQMCParameters, calculate_greens_AVX, device_count,  # noqa: F401
-                   hopping_exponentials, mfma_f64_peak, rdivp, udt_AVX_pivot, vmul)
+                   checkerboard_exponentials, hopping_exponentials, mfma_f64_peak, rdivp, udt_AVX_pivot, vmul)
 
 lib()  # fail loudly at import time if the HIP library has not been built

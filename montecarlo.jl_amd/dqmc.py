@@ -62,6 +62,59 @@ def hopping_exponentials(T, delta_tau):
     return eT, eTinv, eT @ eT, eTinv @ eTinv
 
 
+def checkerboard_exponentials(T, lattice, delta_tau):
+    """CheckerboardTrue (init_checkerboard_matrices, stack.jl:185-235; slice_matrices.jl:79-222;
+    _greens! DQMC.jl:731-750) as the four constant matrices of the dense code path.  The reference
+    keeps one sparse matrix per bond group, chkr_hop_half[g] = exp(-dtau/2 Tg) with
+    Tg[trg, src] = T[trg, src] over the group's (disjoint) bonds, and applies
+        B_l      = H_n ... H_2 C_1 H_2 ... H_n Mu eV_l,       C_1 = chkr_hop[1],  Mu = exp(-dtau diag(T))
+        B_l^-1   = eV_l^-1 Mu^-1 (H_n ... H_2 C_1 H_2 ... H_n)^-1
+        greens() = H_1^-1 ... H_n^-1  G  H_n ... H_1
+    group by group.  On MI355X a pass of O(n^2 groups) sparse row updates is HBM-bound and slower than one
+    MFMA GEMM at these sizes, so the group products are multiplied out once here (same order of factors)
+    and handed to the same kernels: eT2 -> P Mu, eTinv2 -> Mu^-1 P^-1, eT -> H_n...H_1, eTinv -> its inverse."""
+    from .lattices import build_checkerboard
+    from scipy.linalg import expm
+    N = T.shape[0]
+    cb, groups, n_groups = build_checkerboard(lattice)
+
+    def rem_eff_zeros(X):  # stack.jl:184
+        X = X.copy()
+        X[np.abs(X) < 1e-15] = 0.0
+        return X
+
+    H, Hinv, Cm, Cinv = [], [], [], []
+    for (gs, ge) in groups:
+        Tg = np.zeros((N, N))
+        for i in range(gs, ge + 1):
+            src, trg = cb[0, i - 1], cb[1, i - 1]
+            Tg[trg - 1, src - 1] = T[trg - 1, src - 1]
+        H.append(rem_eff_zeros(expm(-0.5 * delta_tau * Tg)))
+        Hinv.append(rem_eff_zeros(expm(0.5 * delta_tau * Tg)))
+        Cm.append(rem_eff_zeros(expm(-delta_tau * Tg)))
+        Cinv.append(rem_eff_zeros(expm(delta_tau * Tg)))
+    mus = np.diag(T)
+    Mu, Muinv = np.diag(np.exp(-delta_tau * mus)), np.diag(np.exp(delta_tau * mus))
+
+    def sandwich(half, full):  # the factor applied by multiply_slice_matrix_left! (slice_matrices.jl:109-121)
+        M = np.eye(N)
+        for i in reversed(range(1, n_groups)):
+            M = half[i] @ M
+        M = full[0] @ M
+        for i in range(1, n_groups):
+            M = half[i] @ M
+        return M
+
+    P, Pinv = sandwich(H, Cm), sandwich(Hinv, Cinv)
+    eT = np.eye(N)
+    for i in reversed(range(n_groups)):     # target * chkr_hop_half[i], i = n..1
+        eT = eT @ H[i]
+    eTinv = np.eye(N)
+    for i in reversed(range(n_groups)):     # chkr_hop_half_inv[i] * target, i = n..1
+        eTinv = Hinv[i] @ eTinv
+    return eT, eTinv, P @ Mu, Muinv @ Pinv
+
+
 class DQMCAnalysis:
     """DQMC.jl:36-47 for one walker"""
 
@@ -81,8 +134,10 @@ class DQMC:
     on how walkers are distributed over devices."""
 
     def __init__(self, model, n_walkers=1, device_id=0, seed=123, first_walker=0, thermalization=100, sweeps=100,
-                 safe_mult=10, measure_rate=10, check_sign_problem=True, check_propagation_error=True, **kw):
+                 safe_mult=10, measure_rate=10, check_sign_problem=True, check_propagation_error=True,
+                 checkerboard=False, **kw):
         self.model = model
+        self.checkerboard = bool(checkerboard)
         self.p = DQMCParameters.resolve(thermalization=thermalization, sweeps=sweeps, safe_mult=safe_mult,
                                         measure_rate=measure_rate, check_sign_problem=check_sign_problem,
                                         check_propagation_error=check_propagation_error, **kw)
@@ -91,11 +146,16 @@ class DQMC:
         self.nb = model.flv
         self.last_sweep = 0
         Ts = model.hopping_matrix()
-        exps = [hopping_exponentials(T, self.p.delta_tau) for T in Ts]
+        if self.checkerboard:  # DQMC(m; checkerboard=true) (DQMC.jl:250-263)
+            exps = [checkerboard_exponentials(T, model.l, self.p.delta_tau) for T in Ts]
+        else:
+            exps = [hopping_exponentials(T, self.p.delta_tau) for T in Ts]
         cat = lambda k: np.ascontiguousarray(np.concatenate([e[k].reshape(-1, order="F") for e in exps]))
         self._eT, self._eTinv, self._eT2, self._eTinv2 = cat(0), cat(1), cat(2), cat(3)
         self.hopping_matrix_exp = [e[0] for e in exps]
         self.hopping_matrix_exp_inv = [e[1] for e in exps]
+        self.hopping_matrix_exp_squared = [e[2] for e in exps]
+        self.hopping_matrix_exp_inv_squared = [e[3] for e in exps]
         prm = _lib.Params(self.N, model.kind, self.p.slices, self.p.safe_mult, n_walkers, device_id,
                           int(self.p.check_propagation_error), int(self.p.check_sign_problem), self.p.delta_tau,
                           model.U, dptr(self._eT), dptr(self._eTinv), dptr(self._eT2), dptr(self._eTinv2))

@@ -211,7 +211,7 @@ class OracleDQMC:
     """Mirror of the reference DQMC object for one chain (DQMC.jl:133-189)."""
 
     def __init__(self, L, model="attractive", beta=1.0, delta_tau=0.1, safe_mult=10, U=1.0, t=1.0,
-                 mu=0.0, check_propagation_error=True, check_sign_problem=True, hopping=None):
+                 mu=0.0, check_propagation_error=True, check_sign_problem=True, hopping=None, exps=None):
         self.L = L
         self.N = L * L if hopping is None else hopping.shape[0]
         self.model = ATTRACTIVE if model == "attractive" else REPULSIVE
@@ -223,7 +223,8 @@ class OracleDQMC:
         if hopping is None:
             hopping = hopping_square(L, t, mu if self.model == ATTRACTIVE else 0.0)
         self.T = hopping
-        eT, eTinv, eT2, eTinv2 = hopping_exponentials(self.T, delta_tau)
+        # exps: the four constant matrices handed over explicitly (e.g. the checkerboard group products)
+        eT, eTinv, eT2, eTinv2 = [F(e) for e in exps] if exps is not None else hopping_exponentials(self.T, delta_tau)
         self.eT, self.eTinv, self.eT2, self.eTinv2 = eT, eTinv, eT2, eTinv2
         rep = lambda a: F(np.concatenate([a.reshape(-1, order="F")] * self.nb))
         self._c = [rep(eT), rep(eTinv), rep(eT2), rep(eTinv2)]
