@@ -37,6 +37,7 @@ struct dqmc_handle {
     double *Ul = nullptr, *Ur = nullptr, *Tl = nullptr, *Tr = nullptr, *greens = nullptr, *greens_temp = nullptr;
     double *tmp1 = nullptr, *tmp2 = nullptr, *bufA = nullptr, *bufB = nullptr;
     double *qrV = nullptr, *qrW = nullptr, *qrS = nullptr;
+    double *trsm_w = nullptr;  // inverted 16 x 16 diagonal blocks (launch_trsm_right_upper)
     double *Dl = nullptr, *Dr = nullptr, *tau = nullptr;
     int *pivot = nullptr;
     double *sU = nullptr, *sVT = nullptr;
@@ -273,7 +274,7 @@ static int udt(dqmc_handle *h, double *A, double *Uout, double *Dout, double *To
     {
         Timed t(h, DQMC_K_TRSM);
         HIPCHK(launch_trsm_right_upper(n, h->units, h->qrV, h->nn, h->qrS, h->nn, nullptr, h->tau, n, h->qrW, h->nn,
-                                       h->stream));
+                                       h->trsm_w, h->stream));
     }
     g = gemm_base(h, U_(h, h->qrW), 0, U_(h, h->qrV), 1, Uout);
     g.alpha = -1.0;
@@ -284,7 +285,8 @@ static int udt(dqmc_handle *h, double *A, double *Uout, double *Dout, double *To
 static int rdivp(dqmc_handle *h, double *A, const double *T)
 {
     Timed t(h, DQMC_K_TRSM);
-    HIPCHK(launch_trsm_right_upper(h->n, h->units, A, h->nn, T, h->nn, h->pivot, nullptr, 0, A, h->nn, h->stream));
+    HIPCHK(launch_trsm_right_upper(h->n, h->units, A, h->nn, T, h->nn, h->pivot, nullptr, 0, A, h->nn, h->trsm_w,
+                                   h->stream));
     return 0;
 }
 
@@ -602,6 +604,7 @@ int dqmc_create(const dqmc_params *p, dqmc_handle **out)
                        &h->tmp2, &h->bufA, &h->bufB, &h->qrV, &h->qrW, &h->qrS};
     for (auto m : mats) CCHK(dalloc(h, m, un));
     CCHK(dalloc(h, &h->Dl, uv)); CCHK(dalloc(h, &h->Dr, uv)); CCHK(dalloc(h, &h->tau, uv));
+    CCHK(dalloc(h, &h->trsm_w, (size_t)h->units * ((h->n + 15) / 16) * 256));
     CCHK(dalloc(h, &h->pivot, uv));
     CCHK(alloc_qr_workspace(h));
     CCHK(dalloc(h, &h->sU, (size_t)h->units * h->n * h->kd));
@@ -1205,6 +1208,7 @@ static int scratch_udt_bufs(dqmc_handle *h)
     const size_t un = (size_t)h->units * h->nn, uv = (size_t)h->units * h->n;
     CHK(dalloc(h, &h->qrV, un)); CHK(dalloc(h, &h->qrW, un)); CHK(dalloc(h, &h->qrS, un));
     CHK(dalloc(h, &h->tau, uv)); CHK(dalloc(h, &h->pivot, uv));
+    CHK(dalloc(h, &h->trsm_w, (size_t)h->units * ((h->n + 15) / 16) * 256));
     CHK(alloc_qr_workspace(h));
     return 0;
 }
@@ -1238,6 +1242,7 @@ int dqmc_rdivp(int32_t device_id, int32_t n, int32_t batch, double *A, const dou
     const size_t un = (size_t)batch * h->nn, uv = (size_t)batch * n;
     double *dA, *dT;
     SCHK(dalloc(h, &dA, un, false)); SCHK(dalloc(h, &dT, un, false)); SCHK(dalloc(h, &h->pivot, uv));
+    SCHK(dalloc(h, &h->trsm_w, (size_t)h->units * ((h->n + 15) / 16) * 256));
     std::vector<int> piv(uv);
     for (size_t i = 0; i < uv; ++i) {
         if (pivot[i] < 1 || pivot[i] > n) { scratch_free(h); return fail(nullptr, DQMC_ERR_INVALID, "pivot entry out of range"); }

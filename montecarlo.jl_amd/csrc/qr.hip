@@ -935,21 +935,51 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 constexpr int TM_XS = 40;    // LDS stride of an X column (32 rows + pad: conflict-free MFMA operand reads)
 constexpr int TM_TS = 258;   // LDS stride of a T panel column (2*TS = 4 mod 64 dwords: conflict-free)
 
+// Inverses of the 16 x 16 diagonal blocks of T (upper triangular; reciprocal diagonal either 1/T[c,c] or
+// dmul[c]), one workgroup of 16 threads per (block, unit): thread j builds column j of W = B^-1 by back
+// substitution.  With them the in-block solve of the main kernel is one small MFMA product instead of a
+// 16-step substitution on 16 lanes.  Rows/columns beyond n are the identity.
+__global__ __launch_bounds__(16) void trsm_diag_inv_kernel(int n, const double *__restrict__ Tall, long sT,
+                                                          const double *__restrict__ dmulall, long sV,
+                                                          double *__restrict__ Wall, int nblk)
+{
+    __shared__ double B[16][17], rdg[16];
+    const int J = blockIdx.x, unit = blockIdx.y, j = threadIdx.x, j0 = J << 4;
+    const double *__restrict__ T = Tall + (long)unit * sT;
+    const double *__restrict__ dmul = dmulall ? dmulall + (long)unit * sV : nullptr;
+    double *__restrict__ W = Wall + ((long)unit * nblk + J) * 256;
+    const int col = j0 + j;
+    for (int i = 0; i < 16; ++i) B[i][j] = (col < n && j0 + i < n && i < j) ? T[(j0 + i) + (long)n * col] : 0.0;
+    rdg[j] = col < n ? (dmul ? dmul[col] : 1.0 / T[col + (long)n * col]) : 1.0;
+    __syncthreads();
+    double wcol[16];
+#pragma unroll
+    for (int i = 15; i >= 0; --i) {
+        double sum = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+        for (int kk = i + 1; kk < 16; ++kk) sum -= B[i][kk] * ((kk <= j) ? wcol[kk] : 0.0);
+        wcol[i] = (i <= j) ? sum * rdg[i] : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) W[i + 16 * j] = wcol[i];  // column-major 16 x 16
+}
+
 __global__ __launch_bounds__(128) void trsm_mfma_kernel(int n, const double *__restrict__ Aall, long sA,
                                                        const double *__restrict__ Tall, long sT,
                                                        const int *__restrict__ pivall,
                                                        const double *__restrict__ dmulall, long sV,
-                                                       double *__restrict__ Oall, long sO, int slabs)
+                                                       double *__restrict__ Oall, long sO, int slabs,
+                                                       const double *__restrict__ Wall)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double *Xs = sm;                   // [256][TM_XS]
     double *Tp = Xs + 256 * TM_XS;     // [16][TM_TS]  panel T[0 : j0+16, j0 : j0+16], column c at Tp + c*TM_TS
-    double *rd = Tp + 16 * TM_TS;      // [16] reciprocal diagonal (or dmul)
+    double *Wl = Tp + 16 * TM_TS;      // [16][18] inverse of the current diagonal block, W[k][c] at Wl + c*18 + k
     const int unit = blockIdx.x / slabs, row0 = (blockIdx.x % slabs) * 32;
     const double *__restrict__ A = Aall + (long)unit * sA;
     const double *__restrict__ T = Tall + (long)unit * sT;
     const int *__restrict__ piv = pivall ? pivall + (long)unit * n : nullptr;
-    const double *__restrict__ dmul = dmulall ? dmulall + (long)unit * sV : nullptr;
+    (void)dmulall; (void)sV;  // the diagonal enters through the inverted blocks
     double *__restrict__ O = Oall + (long)unit * sO;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int li = lane & 15, lq = lane >> 4;
@@ -960,19 +990,25 @@ __global__ __launch_bounds__(128) void trsm_mfma_kernel(int n, const double *__r
         Xs[j * TM_XS + r] = row < n ? A[row + (long)n * pj] : 0.0;
     }
     const int nblk = (n + 15) >> 4;
+    for (int idx = n * 32 + tid; idx < nblk * 16 * 32; idx += 128) Xs[(idx >> 5) * TM_XS + (idx & 31)] = 0.0;  // columns >= n
+    const double *__restrict__ Wu = Wall + (long)unit * nblk * 256;
     // the T panel of block J+1 is requested from global memory (L2) while block J computes:
     // thread (c = tid >> 3) holds k = (tid & 7) + 8 i of column j0 + c in registers until the LDS panel is free
-    double pre[32], pre_rd = 0.0;
+    double pre[32], pre_w[2] = {0.0, 0.0};
     auto fetch_panel = [&](int J) {
-        const int j0 = J << 4, c = tid >> 3, col = j0 + c;
+        // no per-lane predicates: entries below the diagonal are never used (the product reads rows
+        // k < j0 <= col, the substitution rows j0 + c2 < col), indices are clamped into the matrix, and
+        // the number of 8-row steps is wave-uniform
+        const int j0 = J << 4, c = tid >> 3, col = min(j0 + c, n - 1);
+        const int steps = J < nblk ? (min(j0 + 16, n) + 7) >> 3 : 0;
+        const double *__restrict__ tc = T + (long)n * col;
 #pragma unroll
         for (int i = 0; i < 32; ++i) {
-            const int k = (tid & 7) + 8 * i;
-            pre[i] = (J < nblk && k < j0 + 16 && col < n && k <= col) ? T[k + (long)n * col] : 0.0;
+            if (i < steps) pre[i] = tc[min((tid & 7) + 8 * i, n - 1)];
         }
-        if (tid < 16) {
-            const int cc = j0 + tid;
-            pre_rd = (J < nblk && cc < n) ? (dmul ? dmul[cc] : 1.0 / T[cc + (long)n * cc]) : 0.0;
+        if (J < nblk) {
+            pre_w[0] = Wu[(long)J * 256 + tid];
+            pre_w[1] = Wu[(long)J * 256 + 128 + tid];
         }
     };
     fetch_panel(0);
@@ -980,51 +1016,48 @@ __global__ __launch_bounds__(128) void trsm_mfma_kernel(int n, const double *__r
         const int j0 = J << 4;
         __syncthreads();  // previous block's panel no longer read; first pass: Xs complete
         {
-            const int c = tid >> 3;
+            const int c = tid >> 3, steps = (min(j0 + 16, n) + 7) >> 3;  // as fetched: wave-uniform
 #pragma unroll
             for (int i = 0; i < 32; ++i) {
-                const int k = (tid & 7) + 8 * i;
-                if (k < j0 + 16) Tp[c * TM_TS + k] = pre[i];
+                if (i < steps) Tp[c * TM_TS + (tid & 7) + 8 * i] = pre[i];
             }
-            if (tid < 16) rd[tid] = pre_rd;
+            Wl[(tid >> 4) * 18 + (tid & 15)] = pre_w[0];
+            Wl[((tid + 128) >> 4) * 18 + (tid & 15)] = pre_w[1];
         }
         __syncthreads();
         fetch_panel(J + 1);
         // acc[i = lq + 4 r][c = li] = sum_{k < j0} X[16 w + i, k] T[k, j0 + c]; two independent
         // accumulators (a dependent MFMA chain would expose the 64+ cycle MFMA latency per k-step)
         d4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-        int kk = 0;
-        for (; kk + 8 <= j0; kk += 8) {
-            const double a0 = Xs[(kk + lq) * TM_XS + 16 * w + li], b0 = Tp[li * TM_TS + kk + lq];
-            const double a1 = Xs[(kk + 4 + lq) * TM_XS + 16 * w + li], b1 = Tp[li * TM_TS + kk + 4 + lq];
-            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc1, 0, 0, 0);
-        }
-        for (; kk < j0; kk += 4) {
-            const double a = Xs[(kk + lq) * TM_XS + 16 * w + li];
-            const double b = Tp[li * TM_TS + kk + lq];
-            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc0, 0, 0, 0);
+        // j0 is a multiple of 16: steps of 16 k with all eight operand reads issued before the MFMAs
+        const double *xa = Xs + lq * TM_XS + 16 * w + li, *tb = Tp + li * TM_TS + lq;
+        for (int kk = 0; kk < j0; kk += 16) {
+            double a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a[u] = xa[(kk + 4 * u) * TM_XS];
+                b[u] = tb[kk + 4 * u];
+            }
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b[1], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], b[2], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], b[3], acc1, 0, 0, 0);
         }
         const d4_t acc = acc0 + acc1;
 #pragma unroll
         for (int r = 0; r < 4; ++r) Xs[(j0 + li) * TM_XS + 16 * w + lq + 4 * r] -= acc[r];
-        // substitution inside the block: lane = row (the wave's own 16 rows; LDS ops of one wave are ordered)
-        if (lane < 16) {
-            double xs[16];
-            const int row = 16 * w + lane;
+        // in-block solve X_J = R_J W_J with the precomputed inverse of the diagonal block: four k-steps on the
+        // wave's own 16 rows (LDS ops of one wave are ordered: the subtraction above is visible)
+        {
+            d4_t xacc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                double x = Xs[(j0 + c) * TM_XS + row], x2 = 0.0;  // two partial sums: shorter FMA chains
-#pragma unroll
-                for (int c2 = 0; c2 + 1 < c; c2 += 2) {
-                    x -= xs[c2] * Tp[c * TM_TS + j0 + c2];
-                    x2 -= xs[c2 + 1] * Tp[c * TM_TS + j0 + c2 + 1];
-                }
-                if (c & 1) x -= xs[c - 1] * Tp[c * TM_TS + j0 + c - 1];
-                x = (x + x2) * rd[c];
-                xs[c] = x;
-                Xs[(j0 + c) * TM_XS + row] = x;
+            for (int u = 0; u < 4; ++u) {
+                const double a = Xs[(j0 + 4 * u + lq) * TM_XS + 16 * w + li];
+                const double b = Wl[li * 18 + 4 * u + lq];
+                xacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, xacc, 0, 0, 0);
             }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Xs[(j0 + li) * TM_XS + 16 * w + lq + 4 * r] = xacc[r];
         }
     }
     __syncthreads();
@@ -1036,12 +1069,13 @@ __global__ __launch_bounds__(128) void trsm_mfma_kernel(int n, const double *__r
 
 hipError_t launch_trsm_right_upper(int n, int n_units, const double *A, long sA, const double *T, long sT,
                                    const int *pivot, const double *dmul, long sV, double *Out, long sO,
-                                   hipStream_t s)
+                                   double *winv, hipStream_t s)
 {
     static const bool no_mfma = getenv("DQMC_TRSM_SIMPLE") != nullptr;
-    if (n <= 256 && !no_mfma) {
-        const int slabs = (n + 31) / 32;
-        const size_t lds = (256 * TM_XS + 16 * TM_TS + 16) * sizeof(double);
+    if (n <= 256 && winv && !no_mfma) {
+        const int slabs = (n + 31) / 32, nblk = (n + 15) / 16;
+        hipLaunchKernelGGL(trsm_diag_inv_kernel, dim3(nblk, n_units), dim3(16), 0, s, n, T, sT, dmul, sV, winv, nblk);
+        const size_t lds = (256 * TM_XS + 16 * TM_TS + 16 * 18) * sizeof(double);
         static bool attr_set = false;
         if (!attr_set) {
             (void)hipFuncSetAttribute((const void *)trsm_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1049,7 +1083,7 @@ hipError_t launch_trsm_right_upper(int n, int n_units, const double *A, long sA,
             attr_set = true;
         }
         hipLaunchKernelGGL(trsm_mfma_kernel, dim3(n_units * slabs), dim3(128), lds, s, n, A, sA, T, sT, pivot, dmul,
-                           sV, Out, sO, slabs);
+                           sV, Out, sO, slabs, winv);
         return hipGetLastError();
     }
     // slab height: largest of 64/32/16 whose LDS image fits
