@@ -106,12 +106,16 @@ __global__ __launch_bounds__(MAXT) void sweep_chunk_kernel(int n, int nb, int mo
 
     // G0[:, site] and G0[site, :] for one group of sites, requested one group ahead
     double colr[SW_GROUP], rowr[SW_GROUP], coln[SW_GROUP], rown[SW_GROUP];
+    // no per-lane predicates: padding lanes read row/column n-1, sites past the chunk re-read the last one
+    // (their values are never used); a group that lies entirely past the chunk is skipped by a uniform branch
+    const int tq = active ? t : n - 1;
     auto fetch = [&](int s0, double (&cc)[SW_GROUP], double (&rr)[SW_GROUP]) {
+        if (s0 >= nsites) return;
 #pragma unroll
         for (int q = 0; q < SW_GROUP; ++q) {
-            const bool ok = active && s0 + q < nsites;
-            cc[q] = ok ? G[t + (long)n * (site0 + s0 + q)] : 0.0;
-            rr[q] = ok ? G[(site0 + s0 + q) + (long)n * t] : 0.0;
+            const int site = site0 + min(s0 + q, nsites - 1);
+            cc[q] = G[tq + (long)n * site];
+            rr[q] = G[site + (long)n * tq];
         }
     };
     fetch(0, colr, rowr);
