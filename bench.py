@@ -92,6 +92,8 @@ def main():
     import torch
     dist = None
     if world > 1 or os.environ.get("BENCH_FORCE_DIST"):  # the env var exercises the RCCL path on one rank
+        for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533")):
+            os.environ.setdefault(k, v)  # torchrun sets these; a bare single-rank rehearsal does not
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
