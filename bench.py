@@ -172,7 +172,7 @@ def main():
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
                      "traffic_note": "bytes per full 256^3 x 32 GEMM launch, from profiles/*_pmc_gemm.json",
-                     "kernel": "gemm_kernel (v_mfma_f64_16x16x4_f64)", "launches_per_sweep": gemm_launches / t_steps,
+                     "kernel": "GEMM family: gemm_kernel<TA,TB> + gemm_flush_kernel (v_mfma_f64_16x16x4_f64)", "launches_per_sweep": gemm_launches / t_steps,
                      "avg_launch_us": gemm_ms * 1e3 / max(1, gemm_launches)},
         "whole_sweep": {"algorithmic_gflop_per_walker_sweep": F["total"] / 1e9,
                         "achieved_tflops": F["total"] * value / n_gpus / 1e12,

@@ -496,6 +496,24 @@ static int sweep_spatial(dqmc_handle *h)
                                       site0, ns, h->sU, h->sVT, (long)h->n * h->kd, h->sc, h->rng, h->stats,
                                       h->p.check_sign_problem, h->stream));
         }
+        if (h->n % 64 == 0 && h->kd == 64) {  // dedicated flush kernel (whole K in LDS, C requested first)
+            hipEvent_t a = nullptr, b = nullptr;
+            if (h->timing) {
+                auto get = [&]() {
+                    hipEvent_t ev;
+                    if (!h->pool.empty()) { ev = h->pool.back(); h->pool.pop_back(); }
+                    else (void)hipEventCreate(&ev);
+                    return ev;
+                };
+                a = get(); b = get();
+            }
+            HIPCHK(launch_gemm_flush(h->n, h->units, h->sU, h->sVT, (long)h->n * h->kd, h->greens, h->nn, h->stream, a, b));
+            if (h->timing) {
+                h->pending.push_back({a, b, DQMC_K_GEMM});
+                if (h->pending.size() >= 2048) CHK(timing_drain(h));
+            }
+            continue;
+        }
         GemmArgs g = gemm_base(h, mat(h->sU, (long)h->n * h->kd, h->n), 0, mat(h->sVT, (long)h->n * h->kd, h->n), 1,
                                h->greens);
         g.K = h->kd;

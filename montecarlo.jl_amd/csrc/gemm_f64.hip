@@ -187,6 +187,93 @@ hipError_t launch_gemm(const GemmArgs &g, hipStream_t s, hipEvent_t start, hipEv
     return hipGetLastError();
 }
 
+// Flush of the delayed Sherman-Morrison updates: C += U V' with K = 64 slots (sweep.hip keeps
+// U'[t][m] at U[t + n m] and V[m][t] at VT[t + n m]).  The whole K extent of both operands fits LDS at
+// once (2 x 40 KB), so there is one barrier instead of the generic kernel's four pipelined k-tiles, and
+// the C tile is requested before anything else: the kernel is bound by that read-modify-write.
+// Requires n % 64 == 0; same tile -> wave -> lane mapping and XCD-aware block map as gemm_kernel.
+constexpr int FK = 64;
+__global__ __launch_bounds__(256) void gemm_flush_kernel(int n, int n_units, const double *__restrict__ Uall,
+                                                        const double *__restrict__ VTall, long sUV,
+                                                        double *__restrict__ Call, long sC, int tiles_m, int tiles_n)
+{
+    extern __shared__ __attribute__((aligned(16))) double fsm[];
+    double(*As)[LS] = reinterpret_cast<double(*)[LS]>(fsm);             // [FK][LS]: U tile, m contiguous
+    double(*Bs)[LS] = reinterpret_cast<double(*)[LS]>(fsm + FK * LS);   // [FK][LS]: V' tile, n contiguous
+    const int bid = blockIdx.x, xcd = bid & 7, seq = bid >> 3;
+    const int T = tiles_m * tiles_n;
+    const int unit = (seq / T) * 8 + xcd;
+    if (unit >= n_units) return;
+    const int tile = seq % T;
+    const int m0 = (tile % tiles_m) * BM, n0 = (tile / tiles_m) * BN;
+    const double *__restrict__ U = Uall + (long)unit * sUV;
+    const double *__restrict__ VT = VTall + (long)unit * sUV;
+    double *__restrict__ C = Call + (long)unit * sC;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave & 1) * 32, wn = (wave >> 1) * 32;
+    const int li = lane & 15, lq = lane >> 4;
+
+    // C tile first: lane holds C[m = .. + li][n = .. + lq + 4r]
+    d4 acc[2][2];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                acc[ti][tj][r] = C[(long)n * (n0 + wn + tj * 16 + lq + 4 * r) + m0 + wm + ti * 16 + li];
+    // operands: 4 passes of 16 k-rows; thread -> k = pass*16 + tid/16, 4 consecutive m (resp. n)
+    const int kr = tid >> 4, c4 = (tid & 15) << 2;
+    double ra[4][4], rb[4][4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const double *qa = U + (long)n * (p * 16 + kr) + m0 + c4;
+        const double *qb = VT + (long)n * (p * 16 + kr) + n0 + c4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { ra[p][i] = qa[i]; rb[p][i] = qb[i]; }
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        double *da = &As[p * 16 + kr][c4], *db = &Bs[p * 16 + kr][c4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { da[i] = ra[p][i]; db[i] = rb[p][i]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < FK; kk += 4) {
+        const int kq = kk + lq;
+        const double a0 = As[kq][wm + li], a1 = As[kq][wm + 16 + li];
+        const double b0 = Bs[kq][wn + li], b1 = Bs[kq][wn + 16 + li];
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a0, acc[0][0], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a1, acc[1][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a0, acc[0][1], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a1, acc[1][1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                C[(long)n * (n0 + wn + tj * 16 + lq + 4 * r) + m0 + wm + ti * 16 + li] = acc[ti][tj][r];
+}
+hipError_t launch_gemm_flush(int n, int n_units, const double *U, const double *VT, long sUV, double *C, long sC,
+                             hipStream_t s, hipEvent_t start, hipEvent_t stop)
+{
+    if (n % 64 != 0) return hipErrorInvalidValue;
+    const int tm = n / BM, tn = n / BN;
+    const int groups = (n_units + 7) / 8;
+    const size_t lds = 2 * (size_t)FK * LS * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)gemm_flush_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipExtLaunchKernelGGL(gemm_flush_kernel, dim3(groups * 8 * tm * tn), dim3(256), lds, s, start, stop, 0, n, n_units, U,
+                          VT, sUV, C, sC, tm, tn);
+    return hipGetLastError();
+}
+
 // fp64 MFMA peak probe: independent accumulators, no memory traffic.
 __global__ __launch_bounds__(256) void mfma_peak_kernel(int iters, double *sink)
 {

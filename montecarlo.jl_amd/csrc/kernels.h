@@ -67,6 +67,9 @@ struct GemmArgs {
 // start/stop (optional): events that take the dispatch's own begin/end timestamps (hipExtLaunchKernelGGL),
 // i.e. the kernel-only duration a profiler's kernel trace reports
 hipError_t launch_gemm(const GemmArgs &g, hipStream_t s, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
+// C += U V' for the delayed-update flush: U[t + n m], VT[t + n m], m < 64 slots; n % 64 == 0
+hipError_t launch_gemm_flush(int n, int n_units, const double *U, const double *VT, long sUV, double *C, long sC,
+                             hipStream_t s, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
 
 // Column-pivoted Householder QR, in place (udt_AVX_pivot! "QR decomposition" loop,
 // src/linalg/UDT.jl:212-246).  On exit A holds R on/above the diagonal and the
