@@ -569,6 +569,33 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v)
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// reflectorApply! (UDT.jl:32-50) on one register-resident column, followed by its fresh squared norm.
+// KB0 = first live block of 8 rows: in the region of steps 32 R .. 32 R + 31 rows below 32 R are finished
+// (the reflector is zero there), so blocks k < 4 R cost nothing at compile time.
+template <int KB0>
+__device__ __forceinline__ double qc_apply(double (&x)[32], const double *vq, double tj, int j, int rg)
+{
+    double2 vv[16];
+    double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+    for (int k = KB0; k < 32; k += 2) {
+        vv[k >> 1] = *reinterpret_cast<const double2 *>(vq + k);
+        d0 += vv[k >> 1].x * x[k];
+        d1 += vv[k >> 1].y * x[k + 1];
+    }
+    const double wv = sum8(d0 + d1) * tj;
+    double n0 = 0.0, n1 = 0.0;
+#pragma unroll
+    for (int k = KB0; k < 32; k += 2) {
+        const double y0 = x[k] - vv[k >> 1].x * wv, y1 = x[k + 1] - vv[k >> 1].y * wv;
+        x[k] = y0;
+        x[k + 1] = y1;
+        n0 += (rg + 8 * k > j ? 1.0 : 0.0) * (y0 * y0);
+        n1 += (rg + 8 * (k + 1) > j ? 1.0 : 0.0) * (y1 * y1);
+    }
+    return sum8(n0 + n1);
+}
+
 __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double *__restrict__ Aall, long strideA,
                                                      double *__restrict__ tauall, int *__restrict__ pivall,
                                                      double *mailbox, unsigned long long *flags,
@@ -753,25 +780,16 @@ __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double
         // ---- apply H_j to my column if it is still live (reflectorApply!, UDT.jl:32-50); fresh norm
         if (c < n && pos[c] > j) {
             const double *vq = vperm + rg * QT_VS;
-            double2 vv[16];  // the reflector stays in registers for the second pass (LDS pipe is shared by 4 waves)
-            double d0 = 0.0, d1 = 0.0;
-#pragma unroll
-            for (int k = 0; k < 32; k += 2) {
-                vv[k >> 1] = *reinterpret_cast<const double2 *>(vq + k);
-                d0 += vv[k >> 1].x * x[k];
-                d1 += vv[k >> 1].y * x[k + 1];
+            switch (j >> 5) {  // wave-uniform: region of 32 steps -> first live row block
+            case 0: nrm = qc_apply<0>(x, vq, tj, j, rg); break;
+            case 1: nrm = qc_apply<4>(x, vq, tj, j, rg); break;
+            case 2: nrm = qc_apply<8>(x, vq, tj, j, rg); break;
+            case 3: nrm = qc_apply<12>(x, vq, tj, j, rg); break;
+            case 4: nrm = qc_apply<16>(x, vq, tj, j, rg); break;
+            case 5: nrm = qc_apply<20>(x, vq, tj, j, rg); break;
+            case 6: nrm = qc_apply<24>(x, vq, tj, j, rg); break;
+            default: nrm = qc_apply<28>(x, vq, tj, j, rg); break;
             }
-            const double wv = sum8(d0 + d1) * tj;
-            double n0 = 0.0, n1 = 0.0;
-#pragma unroll
-            for (int k = 0; k < 32; k += 2) {
-                const double y0 = x[k] - vv[k >> 1].x * wv, y1 = x[k + 1] - vv[k >> 1].y * wv;
-                x[k] = y0;
-                x[k + 1] = y1;
-                n0 += (rg + 8 * k > j ? 1.0 : 0.0) * (y0 * y0);
-                n1 += (rg + 8 * (k + 1) > j ? 1.0 : 0.0) * (y1 * y1);
-            }
-            nrm = sum8(n0 + n1);
         }
         // (pos/colat are rewritten by thread 0 only after the barriers of the next step)
     }
