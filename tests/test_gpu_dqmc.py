@@ -184,3 +184,20 @@ def test_repeated_udt_launches_are_bit_reproducible(gpu):
                 g = mc.calculate_greens(3, w)
                 assert all(np.array_equal(g[b], first[w][b]) for b in range(2))
         mc.close()
+
+
+@pytest.mark.parametrize("kind,L", [("attractive", 6), ("repulsive", 6), ("attractive", 10)])
+def test_odd_sizes_padding_paths(gpu, O, kind, L):
+    """n = 36 and n = 100 are multiples of neither 8, 16 nor 64: padded lanes in the sweep kernel, partial
+    tiles in the GEMMs, partial blocks in QR / TRSM, the generic (non-flush-kernel) update flush"""
+    mc, refs = make_pair(gpu, O, L, kind, 1.0, n_walkers=2, safe_mult=5)
+    mc.prepare()
+    for o in refs:
+        o.prepare()
+    compare(mc, refs)
+    for _ in range(12):
+        mc.update()
+        for o in refs:
+            o.update()
+    compare(mc, refs)
+    mc.close()
