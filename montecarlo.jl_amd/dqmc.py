@@ -293,10 +293,18 @@ class DQMC:
                     tail[-1] += 1
         return self.accumulators() + tail
 
-    def run(self, verbose=False, on_measure=None, recorder=None):
-        """run!(mc) (DQMC.jl:369-515) without the host-side measurement framework: the
-        true Green's function is accumulated on the device every `measure_rate`-th sweep
-        after thermalization, at current_slice == 1 && direction == +1 (DQMC.jl:425-436)."""
+    def run(self, verbose=False, on_measure=None, recorder=None, measurements=("greens",)):
+        """run!(mc) (DQMC.jl:369-515) without the host-side measurement framework: the selected
+        measurements are accumulated on the device every `measure_rate`-th sweep after thermalization,
+        at current_slice == 1 && direction == +1 (DQMC.jl:425-436).  `measurements` may contain
+        "greens" (greens_measurement, occupation), "correlations" (charge/spin density correlations,
+        magnetization; needs set_pair_directions), "pairing" (needs set_local_targets) and
+        "susceptibilities" (the CombinedGreensIterator measurements)."""
+        known = {"greens": lib().dqmc_accumulate_greens, "correlations": lib().dqmc_accumulate_correlations,
+                 "pairing": lib().dqmc_accumulate_pairing}
+        for m in measurements:
+            if m not in known and m != "susceptibilities":
+                raise ValueError("unknown measurement %r" % (m,))
         self.prepare()
         self.reset_accumulators()
         total = self.p.thermalization + self.p.sweeps
@@ -308,7 +316,11 @@ class DQMC:
                 if cs == 1 and d == 1 and i > self.p.thermalization and recorder is not None:
                     recorder.push(self, i)  # push!(mc.configs, mc, mc.model, i) (DQMC.jl:430)
                 if cs == 1 and d == 1 and i > self.p.thermalization and i % self.p.measure_rate == 0:
-                    self._c(lib().dqmc_accumulate_greens(self._h))
+                    for m in measurements:
+                        if m == "susceptibilities":
+                            self.accumulate_susceptibilities()
+                        else:
+                            self._c(known[m](self._h))
                     if on_measure is not None:
                         on_measure(self, i)
             self.last_sweep = i

@@ -77,3 +77,41 @@ def test_pairing_requires_tables(gpu):
     with pytest.raises(RuntimeError):
         mc.accumulate_pairing()
     mc.close()
+
+
+def test_reference_integration_goldens_on_the_device(gpu):
+    """End to end on the GPU against numbers produced by the reference itself
+    (test/integration_tests.jl:29-75: attractive 4x4, beta = 1; the published means of one seeded
+    Julia run with atol = 4 dtau^2 = 0.04): 32 walkers x 60 measured sweeps, everything - sweeps,
+    true Green's function, charge / spin density correlations over EachSitePairByDistance - on the
+    device through run().  The golden's own standard error reaches 0.019 (integration_tests.jl:50-52)."""
+    import json, os
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "integration_attractive_4x4.json")))
+    model = gpu.HubbardModelAttractive(4, 2)
+    mc = gpu.DQMC(model, beta=1.0, n_walkers=32, seed=2024, thermalization=50, sweeps=60, measure_rate=1)
+    mc.set_pair_directions(gpu.EachSitePairByDistance(model.l))
+    mc.run(measurements=("greens", "correlations"))
+    acc = mc.unpack_accumulators(mc.accumulators())
+    assert acc["count"] == 32 * 60
+    ref = np.array(g["G_mean_colmajor"]).reshape((16, 16), order="F")
+    assert np.abs(acc["G"][0] - ref).max() < g["atol"] + 0.02
+    c = mc.correlations()
+    assert c["count"] == 32 * 60
+    assert np.abs(c["CDC"] - np.array(g["CDC_mean"])).max() < g["atol"] + 0.02
+    assert np.abs(c["SDCx"] - np.array(g["SDCx_mean"])).max() < g["atol"]
+    # structure the reference's result has: on-site first, then four symmetry-equivalent neighbours
+    assert c["CDC"][0] > 1.4 and np.ptp(c["CDC"][1:5]) < 0.02
+    assert np.abs(c["Mz"]).max() == 0.0
+    mc.close()
+
+
+def test_run_with_all_measurements(gpu):
+    model = gpu.HubbardModelRepulsive(4, 2)
+    mc = gpu.DQMC(model, beta=1.0, n_walkers=2, seed=5, thermalization=1, sweeps=4, measure_rate=2)
+    mc.set_local_targets(gpu.EachLocalQuadByDistance(model.l))
+    mc.run(measurements=("greens", "correlations", "pairing", "susceptibilities"))
+    assert mc.unpack_accumulators(mc.accumulators())["count"] == 4
+    assert mc.correlations()["count"] == 4 and mc.pairing()[1] == 4 and mc.susceptibilities()["count"] == 4
+    with pytest.raises(ValueError):
+        mc.run(measurements=("nonsense",))
+    mc.close()
