@@ -235,9 +235,8 @@ static int alloc_qr_workspace(dqmc_handle *h)
     if (h->n > 256) return 0;
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, h->p.device_id));
-    const size_t slots = (size_t)((h->units + 7) / 8) * 8 * 2 * 32;  // units x parity x 32 wave agents
+    const size_t slots = (size_t)((h->units + 7) / 8) * 8 * 2 * 8;  // units x parity x 8 parts
     CHK(dalloc(h, &h->qr_ws.mailbox, slots * QR_COOP_SLOT));
-    CHK(dalloc(h, &h->qr_ws.flags, slots));
     CHK(dalloc(h, &h->qr_ws.errflag, (size_t)1));
     // co-residency: the kernel's 200 VGPRs admit 2 workgroups of 256 threads per CU
     h->qr_ws.max_blocks = prop.multiProcessorCount * 2;

@@ -76,11 +76,10 @@ hipError_t launch_gemm_flush(int n, int n_units, const double *U, const double *
 // Householder vectors below it (unit diagonal implied), tau[n], pivot[n] (0-based:
 // column j of the factored matrix is original column pivot[j]).
 // Workspace of the cooperative (8 workgroups per matrix) QR: mailbox of n_units x 2 x 8 slots of
-// QR_COOP_SLOT doubles, n_units x 2 x 8 tags, an error flag (bounded spins), a launch counter.
+// QR_COOP_SLOT doubles (tagged packets), an error flag (bounded spins), a launch counter.
 constexpr int QR_COOP_SLOT = 528;  // 264 packets of 16 bytes
 struct QrCoopWorkspace {
     double *mailbox = nullptr;
-    unsigned long long *flags = nullptr;
     int *errflag = nullptr;
     unsigned long long epoch = 0;
     int max_blocks = 0;   // launch the cooperative kernel only if its grid fits (co-residency)

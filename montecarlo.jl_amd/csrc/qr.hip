@@ -598,7 +598,7 @@ __device__ __forceinline__ double qc_apply(double (&x)[32], const double *vq, do
 
 __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double *__restrict__ Aall, long strideA,
                                                      double *__restrict__ tauall, int *__restrict__ pivall,
-                                                     double *mailbox, unsigned long long *flags,
+                                                     double *mailbox,
                                                      unsigned long long epoch, int *errflag, int force_sc1)
 {
     __shared__ __attribute__((aligned(16))) double colbuf[256];   // my best column / the winning column
@@ -617,7 +617,6 @@ __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double
     double *__restrict__ tau = tauall + (long)unit * n;
     int *__restrict__ piv = pivall + (long)unit * n;
     qc_word *mb_unit = reinterpret_cast<qc_word *>(mailbox) + (long)unit * 2 * QC_PARTS * QC_MB * 2;
-    (void)flags;
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, rg = lane & 7, cg = lane >> 3;
     const int c = part + 8 * (8 * w + cg);  // my original column
@@ -815,7 +814,7 @@ hipError_t launch_qr_pivot(int n, int n_units, double *A, long strideA, double *
             ws->epoch += 1;
             static const int force_sc1 = getenv("DQMC_QR_SC1") != nullptr;  // write-through packets regardless of placement
             hipLaunchKernelGGL(qr_coop_kernel, dim3(blocks), dim3(256), 0, s, n, n_units, A, strideA, tau, pivot,
-                               ws->mailbox, ws->flags, ws->epoch, ws->errflag, force_sc1);
+                               ws->mailbox, ws->epoch, ws->errflag, force_sc1);
             return hipGetLastError();
         }
     }
