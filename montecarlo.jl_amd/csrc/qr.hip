@@ -603,7 +603,6 @@ __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double
 {
     __shared__ __attribute__((aligned(16))) double colbuf[256];   // my best column / the winning column
     __shared__ __attribute__((aligned(16))) double vperm[8 * QT_VS];
-    __shared__ double dummy[256];
     __shared__ __attribute__((aligned(16))) double wc[4][2];   // per wave: {norm, bits(pos | col << 32)}
     __shared__ __attribute__((aligned(16))) double win[4];     // the step's pivot: {norm, bits(pos | col << 32), part, -}
     __shared__ int pos[256], colat[256];
@@ -682,11 +681,12 @@ __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double
             const int qp = (int)(pc & 0x7fffffff), qc = (int)(pc >> 32);
             if (cq.x > lbn || (cq.x == lbn && qp < lbp)) { lbn = cq.x; lbp = qp; lbc = qc; }
         }
-        // ---- its owner lanes put the column into LDS (wave-uniform branch, dummy sink for other lanes)
+        // ---- its owner lanes put the column into LDS
         if (lbc >= 0 && w == ((lbc >> 3) >> 3)) {
-            double *dst = (cg == ((lbc >> 3) & 7)) ? colbuf : dummy;
+            if (cg == ((lbc >> 3) & 7)) {  // exec-masked: the other lane groups issue no LDS writes at all
 #pragma unroll
-            for (int k = 0; k < 32; ++k) dst[rg + 8 * k] = x[k];
+                for (int k = 0; k < 32; ++k) colbuf[rg + 8 * k] = x[k];
+            }
         }
         __syncthreads();
         // ---- publish: raw column + header as tagged packets; nothing to wait for
