@@ -59,8 +59,12 @@ constexpr int SW_KD = 64;     // sites per chunk = update slots per flush
 // An accept therefore costs O(1) per thread on the critical path instead of a 2*cnt loop.
 // Layout of the dynamic LDS region (doubles unless noted):
 //   UiT[nb][KD][KD], ViT[nb][KD][KD], dg[2][KD], ul[KD], negv[KD], cs[KD] (int), flip[KD] (int)
-template <int MAXT>
-__global__ __launch_bounds__(MAXT) void sweep_chunk_kernel(int n, int nb, int model, double *__restrict__ Gall,
+// MODEL (0 attractive, 1 repulsive) and FULL are compile-time: FULL = no padding lanes (n % 64 == 0) and the
+// chunk is one aligned block of 64 sites, i.e. exactly one wave per block owns the chunk's rows.  PMC counters
+// show the per-site instruction stream (a third of it scalar: exec-mask branches) to be the limiter; the
+// specialisation removes the per-lane predicates and the other model's code from that stream.
+template <int MAXT, int MODEL, bool FULL>
+__global__ __launch_bounds__(MAXT) void sweep_chunk_kernel(int n, int nb, int model_rt, double *__restrict__ Gall,
                                                           long strideG, int8_t *__restrict__ conf_slice,
                                                           long conf_stride, int site0, int nsites,
                                                           double *__restrict__ Uall, double *__restrict__ VTall,
@@ -81,7 +85,9 @@ __global__ __launch_bounds__(MAXT) void sweep_chunk_kernel(int n, int nb, int mo
     const int w = blockIdx.x;
     const int tid = threadIdx.x;
     const int b = tid / npad, t = tid - b * npad;  // wave-uniform block index
-    const bool active = t < n;
+    (void)model_rt;
+    constexpr int model = MODEL;
+    const bool active = FULL ? true : t < n;
     const int unit = w * nb + b;
     const double *__restrict__ G = Gall + (long)unit * strideG;
     double *Uo = Uall + (long)unit * strideUV;   // slot m of thread t at Uo[t + n*m]
@@ -90,7 +96,8 @@ __global__ __launch_bounds__(MAXT) void sweep_chunk_kernel(int n, int nb, int mo
     double *uit = UiT + (size_t)b * KD * KD, *vit = ViT + (size_t)b * KD * KD;
 
     const int sl = t - site0;  // my index inside the chunk, if any
-    const bool in_chunk = active && sl >= 0 && sl < nsites;
+    // FULL: wave-uniform (the wave whose first row is site0), decided on a scalar
+    const bool in_chunk = FULL ? (__builtin_amdgcn_readfirstlane(t) == site0) : (active && sl >= 0 && sl < nsites);
     if (in_chunk) dg[b * KD + sl] = G[t + (long)n * t];
     const WalkerRng rs = rngs[w];
     if (tid < KD) flip[tid] = 0;
@@ -108,12 +115,12 @@ __global__ __launch_bounds__(MAXT) void sweep_chunk_kernel(int n, int nb, int mo
     double colr[SW_GROUP], rowr[SW_GROUP], coln[SW_GROUP], rown[SW_GROUP];
     // no per-lane predicates: padding lanes read row/column n-1, sites past the chunk re-read the last one
     // (their values are never used); a group that lies entirely past the chunk is skipped by a uniform branch
-    const int tq = active ? t : n - 1;
+    const int tq = FULL ? t : (active ? t : n - 1);
     auto fetch = [&](int s0, double (&cc)[SW_GROUP], double (&rr)[SW_GROUP]) {
         if (s0 >= nsites) return;
 #pragma unroll
         for (int q = 0; q < SW_GROUP; ++q) {
-            const int site = site0 + min(s0 + q, nsites - 1);
+            const int site = site0 + (FULL ? s0 + q : min(s0 + q, nsites - 1));
             cc[q] = G[tq + (long)n * site];
             rr[q] = G[site + (long)n * tq];
         }
@@ -141,27 +148,39 @@ __global__ __launch_bounds__(MAXT) void sweep_chunk_kernel(int n, int nb, int mo
                 }
             };
             if (cnt0 > 0) load_batch(0, hu, hv);
-            for (int mb = 0; mb < cnt0; mb += HB) {
+            int mb = 0;
+            for (; mb + HB <= cnt0; mb += HB) {  // full batches: no per-slot tests
                 if (mb + HB < cnt0) load_batch(mb + HB, hun, hvn);
 #pragma unroll
                 for (int k = 0; k < HB; ++k) {
-                    if (mb + k < cnt0) {
-                        const double *ub = uit + (mb + k) * KD + s0, *vb = vit + (mb + k) * KD + s0;
+                    const double *ub = uit + (mb + k) * KD + s0, *vb = vit + (mb + k) * KD + s0;
 #pragma unroll
-                        for (int q = 0; q < SW_GROUP; ++q) {
-                            colr[q] += hu[k] * vb[q];   // G[t, site_q] += U'[t][m] V[m][site_q]
-                            rowr[q] += ub[q] * hv[k];   // G[site_q, t] += U'[site_q][m] V[m][t]
-                        }
+                    for (int q = 0; q < SW_GROUP; ++q) {
+                        colr[q] += hu[k] * vb[q];   // G[t, site_q] += U'[t][m] V[m][site_q]
+                        rowr[q] += ub[q] * hv[k];   // G[site_q, t] += U'[site_q][m] V[m][t]
                     }
                 }
 #pragma unroll
                 for (int k = 0; k < HB; ++k) { hu[k] = hun[k]; hv[k] = hvn[k]; }
             }
+            if (mb < cnt0) {  // last, partial batch (already loaded; slots past the end are clamped copies)
+#pragma unroll
+                for (int k = 0; k < HB - 1; ++k) {
+                    if (mb + k < cnt0) {
+                        const double *ub = uit + (mb + k) * KD + s0, *vb = vit + (mb + k) * KD + s0;
+#pragma unroll
+                        for (int q = 0; q < SW_GROUP; ++q) {
+                            colr[q] += hu[k] * vb[q];
+                            rowr[q] += ub[q] * hv[k];
+                        }
+                    }
+                }
+            }
         }
 #pragma unroll
         for (int q = 0; q < SW_GROUP; ++q) {
             const int s = s0 + q;
-            if (s < nsites) {
+            if (FULL || s < nsites) {
                 const int i = site0 + s;
                 const int c = cs[s];
                 const int ci = c > 0 ? 1 : 0;
@@ -182,7 +201,7 @@ __global__ __launch_bounds__(MAXT) void sweep_chunk_kernel(int n, int nb, int mo
                     p = detratio;
                     r0s = R0; r1s = R1; d0s = D0; d1s = D1;
                 }
-                if (check_sign && detratio < 0.0) {
+                if (MODEL != 0 && check_sign && detratio < 0.0) {  // attractive: detratio = r^2 >= 0
                     if (tid == 0) negv[nneg] = detratio;
                     ++nneg;
                 }
@@ -215,7 +234,8 @@ __global__ __launch_bounds__(MAXT) void sweep_chunk_kernel(int n, int nb, int mo
                     }
                     // cs[s] itself must stay intact: waves drift apart between barriers (a rejected
                     // site has none) and a slower wave may not have read it yet for ITS proposal
-                    if (tid == 0) flip[s] = 1;
+                    if (FULL) { if (__builtin_amdgcn_readfirstlane(tid) == 0) flip[s] = 1; }  // wave 0, same value from every lane
+                    else if (tid == 0) flip[s] = 1;
                     ++cnt;
                     // LDS-only barrier: __syncthreads() would drain the history stores as well
                     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -263,21 +283,29 @@ hipError_t launch_sweep_chunk(int n, int nb, int n_walkers, int model, double *G
     if (threads > 1024 || nsites > SW_KD) return hipErrorInvalidValue;
     dim3 grid(n_walkers), block(threads);
     const size_t lds = ((size_t)nb * 2 * SW_KD * SW_KD + 6 * SW_KD) * sizeof(double) + 64;
-#define SW_LAUNCH(MT)                                                                                            \
+    const bool full = (n % 64 == 0) && (site0 % 64 == 0) && nsites == 64;
+#define SW_LAUNCH3(MT, MD, FL)                                                                                   \
     do {                                                                                                         \
         static bool attr_set = false;                                                                            \
         if (!attr_set) {                                                                                         \
-            (void)hipFuncSetAttribute((const void *)sweep_chunk_kernel<MT>,                                      \
+            (void)hipFuncSetAttribute((const void *)sweep_chunk_kernel<MT, MD, FL>,                              \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                   \
             attr_set = true;                                                                                     \
         }                                                                                                        \
-        hipLaunchKernelGGL((sweep_chunk_kernel<MT>), grid, block, lds, s, n, nb, model, G, strideG, conf_slice,  \
-                           conf_stride, site0, nsites, Uout, VTout, strideUV, sc, rng, stats, check_sign);       \
+        hipLaunchKernelGGL((sweep_chunk_kernel<MT, MD, FL>), grid, block, lds, s, n, nb, model, G, strideG,      \
+                           conf_slice, conf_stride, site0, nsites, Uout, VTout, strideUV, sc, rng, stats,        \
+                           check_sign);                                                                          \
+    } while (0)
+#define SW_LAUNCH(MT)                                                                                            \
+    do {                                                                                                         \
+        if (model == 0) { if (full) SW_LAUNCH3(MT, 0, true); else SW_LAUNCH3(MT, 0, false); }                    \
+        else { if (full) SW_LAUNCH3(MT, 1, true); else SW_LAUNCH3(MT, 1, false); }                               \
     } while (0)
     if (threads <= 256) SW_LAUNCH(256);
     else if (threads <= 512) SW_LAUNCH(512);
     else SW_LAUNCH(1024);
 #undef SW_LAUNCH
+#undef SW_LAUNCH3
     return hipGetLastError();
 }
 
