@@ -108,6 +108,7 @@ __global__ __launch_bounds__(MAXT) void sweep_chunk_kernel(int n, int nb, int mo
         ul[tid] = rs.uniforms ? (d < rs.n_uniforms ? rs.uniforms[d] : 2.0) : philox_uniform(rs.seed, d);
     }
     int ndraw = 0, nneg = 0, exhausted = 0, cnt = 0;
+    double u_next = 0.0;  // ul[ndraw], requested as soon as its predecessor has been consumed
     const double g0 = sc.gamma[0], g1 = sc.gamma[1], e0 = sc.ebos[0], e1 = sc.ebos[1];
     const double du0 = sc.dup[0], du1 = sc.dup[1], dd0 = sc.ddn[0], dd1 = sc.ddn[1];
 
@@ -127,6 +128,7 @@ __global__ __launch_bounds__(MAXT) void sweep_chunk_kernel(int n, int nb, int mo
     };
     fetch(0, colr, rowr);
     __syncthreads();
+    u_next = ul[0];
 
     for (int s0 = 0; s0 < nsites; s0 += SW_GROUP) {
         fetch(s0 + SW_GROUP, coln, rown);
@@ -177,14 +179,18 @@ __global__ __launch_bounds__(MAXT) void sweep_chunk_kernel(int n, int nb, int mo
                 }
             }
         }
+        // the next site's spin and diagonal entries are requested one site ahead: after the barrier of an
+        // accept (they are final then: an accept only touches entries of later sites) or right away on a reject
+        int c_in = cs[s0];
+        double d0_in = dg[s0], d1_in = MODEL != 0 ? dg[KD + s0] : 0.0;
 #pragma unroll
         for (int q = 0; q < SW_GROUP; ++q) {
             const int s = s0 + q;
             if (FULL || s < nsites) {
                 const int i = site0 + s;
-                const int c = cs[s];
+                const int c = c_in;
                 const int ci = c > 0 ? 1 : 0;
-                const double d0 = dg[s];
+                const double d0 = d0_in;
                 double detratio, p, x0, x1 = 0.0, r0s = 0.0, r1s = 0.0, d0s = 0.0, d1s = 0.0;
                 if (model == 0) {  // HubbardModelAttractive.jl:113-127
                     const double gamma = ci ? g1 : g0;
@@ -194,7 +200,7 @@ __global__ __launch_bounds__(MAXT) void sweep_chunk_kernel(int n, int nb, int mo
                     x0 = gamma;  // numerator; the division by r is off the decision path (done on accept)
                     x1 = r;
                 } else {           // HubbardModelRepulsive.jl:128-156,174-191
-                    const double d1 = dg[KD + s];
+                    const double d1 = d1_in;
                     const double D0 = ci ? du1 : du0, D1 = ci ? dd1 : dd0;
                     const double R0 = 1.0 + D0 * (1.0 - d0), R1 = 1.0 + D1 * (1.0 - d1);
                     detratio = R0 * R1;
@@ -208,7 +214,9 @@ __global__ __launch_bounds__(MAXT) void sweep_chunk_kernel(int n, int nb, int mo
                 bool acc;
                 if (p > 1.0) acc = true;  // DQMC.jl:573: rand() is consumed only when p <= 1
                 else {
-                    const double u = ul[ndraw++];
+                    const double u = u_next;
+                    ++ndraw;
+                    u_next = ul[ndraw];  // (one past the chunk's last uniform at most: inside the LDS block, never used)
                     if (u == 2.0) exhausted = 1;
                     acc = u < p;
                 }
@@ -239,6 +247,11 @@ __global__ __launch_bounds__(MAXT) void sweep_chunk_kernel(int n, int nb, int mo
                     ++cnt;
                     // LDS-only barrier: __syncthreads() would drain the history stores as well
                     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    if (q + 1 < SW_GROUP) {  // (reads one entry past the chunk at most: inside the LDS block, unused)
+                        c_in = cs[s + 1];
+                        d0_in = dg[s + 1];
+                        if (MODEL != 0) d1_in = dg[KD + s + 1];
+                    }
                     // eager update of the rest of the group (static q' > q)
                     {
                         const double *ub = uit + j * KD + s0, *vb = vit + j * KD + s0;
@@ -248,6 +261,10 @@ __global__ __launch_bounds__(MAXT) void sweep_chunk_kernel(int n, int nb, int mo
                             rowr[q2] += ub[q2] * newV;
                         }
                     }
+                } else if (q + 1 < SW_GROUP) {
+                    c_in = cs[s + 1];
+                    d0_in = dg[s + 1];
+                    if (MODEL != 0) d1_in = dg[KD + s + 1];
                 }
             }
         }
