@@ -605,7 +605,7 @@ __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double
     __shared__ __attribute__((aligned(16))) double vperm[8 * QT_VS];
     __shared__ __attribute__((aligned(16))) double wc[4][2];   // per wave: {norm, bits(pos | col << 32)}
     __shared__ __attribute__((aligned(16))) double win[4];     // the step's pivot: {norm, bits(pos | col << 32), part, -}
-    __shared__ int pos[256], colat[256];
+    __shared__ int colat[256];  // position -> column (the inverse, pos[my column], lives in a register)
     __shared__ int s_abort;
     __shared__ int xcc_seen[QC_PARTS];
 
@@ -629,7 +629,7 @@ __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double
         nrm += a * a;
     }
     nrm = sum8(nrm);  // full squared norm of column c, in all 8 lanes of the column
-    pos[tid] = tid;
+    int mypos = c;  // pos[c]
     colat[tid] = tid;
     if (tid == 0) s_abort = 0;
     __syncthreads();
@@ -660,9 +660,9 @@ __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double
         const unsigned tag = (unsigned)(epoch * 1024ull + (unsigned long long)j + 1ull);
         // ---- my workgroup's best live column: larger norm first, then smaller position
         {
-            const bool live = c < n && pos[c] >= j;
+            const bool live = c < n && mypos >= j;
             const double bn = wave_max_f64<8>(live ? nrm : -1.0);
-            const unsigned mp = live ? (unsigned)pos[c] : 0xffffffffu;
+            const unsigned mp = live ? (unsigned)mypos : 0xffffffffu;
             const unsigned bp = wave_min_u32<8>((live && nrm == bn) ? mp : 0xffffffffu);
             int bc = -1;
             if (bn >= 0.0) bc = __builtin_amdgcn_readlane(c, __ffsll((long long)__ballot(live && mp == bp)) - 1);
@@ -679,7 +679,10 @@ __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double
             const double2 cq = *reinterpret_cast<const double2 *>(wc[q]);
             const long long pc = __double_as_longlong(cq.y);
             const int qp = (int)(pc & 0x7fffffff), qc = (int)(pc >> 32);
-            if (cq.x > lbn || (cq.x == lbn && qp < lbp)) { lbn = cq.x; lbp = qp; lbc = qc; }
+            const bool better = cq.x > lbn || (cq.x == lbn && qp < lbp);  // selects, no branches
+            lbn = better ? cq.x : lbn;
+            lbp = better ? qp : lbp;
+            lbc = better ? qc : lbc;
         }
         // ---- its owner lanes put the column into LDS
         if (lbc >= 0 && w == ((lbc >> 3) >> 3)) {
@@ -713,15 +716,22 @@ __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double
                 const qc_word *mb = mb_unit + (long)(par * QC_PARTS + (lane >> 1)) * QC_MB * 2;
                 if (!qc_get(mb + 2 * (256 + 2 * (lane & 1)), tag, tag, 0xffffffffu, hv, hw)) s_abort = 1;
             }
-            double bestn = -1.0;
+            // lane 2q holds the norm of part q, lane 2q+1 its {position, column}: give both to both lanes of the
+            // pair, then reduce across the wave on DPP (largest norm, then smallest position; lanes >= 16 idle)
+            const double other = dpp_self_f64<0xB1>(hv);  // quad_perm [1,0,3,2]
+            const double qn = (lane < 2 * QC_PARTS) ? ((lane & 1) ? other : hv) : -1.0;
+            const double qmeta = (lane & 1) ? hv : other;
+            const unsigned qp = (unsigned)__double2loint(qmeta);
+            const int qc = __double2hiint(qmeta);
+            const double bestn = wave_max_f64<2>(qn);
+            const bool cand = qn >= 0.0 && qn == bestn;
+            const unsigned bestp_u = wave_min_u32<2>(cand ? qp : 0xffffffffu);
             int bestp = 0x7fffffff, bestc = -1, bestq = 0;
-#pragma unroll
-            for (int q = 0; q < QC_PARTS; ++q) {  // wave-uniform (SGPR) compares
-                const double qn = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(hv), 2 * q),
-                                                   __builtin_amdgcn_readlane(__double2loint(hv), 2 * q));
-                const int qp = __builtin_amdgcn_readlane(__double2loint(hv), 2 * q + 1);
-                const int qc = __builtin_amdgcn_readlane(__double2hiint(hv), 2 * q + 1);
-                if (qn >= 0.0 && (qn > bestn || (qn == bestn && qp < bestp))) { bestn = qn; bestp = qp; bestc = qc; bestq = q; }
+            if (bestn >= 0.0) {
+                const int wl = __ffsll((long long)__ballot(cand && qp == bestp_u)) - 1;
+                bestp = (int)bestp_u;
+                bestc = __builtin_amdgcn_readlane(qc, wl);
+                bestq = wl >> 1;
             }
             if (lane == 0) {
                 win[0] = bestn;
@@ -730,7 +740,8 @@ __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double
             }
         }
         __syncthreads();
-        if (s_abort) break;
+        // the column now at position j: read here, one barrier before thread 0 rewrites the table below
+        const int cj = colat[j];
         double maxval;
         int jm, cm, wpart;
         {
@@ -738,7 +749,7 @@ __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double
             const long long pc = __double_as_longlong(w01.y);
             maxval = w01.x; jm = (int)(pc & 0x7fffffff); cm = (int)(pc >> 32); wpart = (int)win[2];
         }
-        if (cm < 0) { cm = colat[j]; jm = j; maxval = 0.0; wpart = cm & 7; }  // nothing live: cannot happen for j < n
+        if (cm < 0) { cm = cj; jm = j; maxval = 0.0; wpart = cm & 7; }  // nothing live: cannot happen for j < n
         // ---- the winning column (tagged packets), reflector (UDT.jl:133-148), output column j
         double cv = 0.0;
         {
@@ -751,33 +762,33 @@ __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double
         __syncthreads();
         if (s_abort) break;
         const double xi1 = colbuf[j];
-        double tj = 0.0, nu = 0.0, xi = 1.0;
-        if (maxval != 0.0) {
-            nu = copysign(rootn, xi1);
-            xi = xi1 + nu;
-            tj = xi / nu;
-        }
+        // branch-free: a zero column (maxval == 0) keeps tau = 0 and the column as it is
+        const bool nz = maxval != 0.0;
+        const double nu = nz ? copysign(rootn, xi1) : 1.0;
+        const double xi = nz ? xi1 + nu : 1.0;
+        const double tj = nz ? xi / nu : 0.0;
         {
             const int r = tid;
-            double outv = cv, vr = (r == j) ? 1.0 : 0.0;
-            if (maxval != 0.0) {
-                if (r == j) outv = -nu;
-                else if (r > j) { outv = cv / xi; vr = outv; }
-            }
+            const double scaled = cv / xi;
+            double outv = (nz && r == j) ? -nu : ((nz && r > j) ? scaled : cv);
+            double vr = (r == j) ? 1.0 : ((nz && r > j) ? scaled : 0.0);
             if (r >= n) vr = 0.0;
             vperm[(r & 7) * QT_VS + (r >> 3)] = vr;
             if (part == wpart && r < n) A[r + (long)n * j] = outv;  // the owner writes the finished column
         }
-        if (tid == 0) {
-            if (part == wpart) tau[j] = tj;
-            const int cj = colat[j];  // swap positions j <-> jm (UDT.jl:219-231), replicated everywhere
-            pos[cm] = j;
-            colat[j] = cm;
-            if (jm != j) { pos[cj] = jm; colat[jm] = cj; }
+        // swap positions j <-> jm (UDT.jl:219-231): every thread tracks its own column, thread 0 the table
+        {
+            if (c == cm) mypos = j;
+            else if (c == cj) mypos = jm;  // (cj == cm when jm == j: covered by the first branch)
+            if (tid == 0) {
+                if (part == wpart) tau[j] = tj;
+                colat[j] = cm;
+                if (jm != j) colat[jm] = cj;
+            }
         }
         __syncthreads();
         // ---- apply H_j to my column if it is still live (reflectorApply!, UDT.jl:32-50); fresh norm
-        if (c < n && pos[c] > j) {
+        if (c < n && mypos > j) {
             const double *vq = vperm + rg * QT_VS;
             switch (j >> 5) {  // wave-uniform: region of 32 steps -> first live row block
             case 0: nrm = qc_apply<0>(x, vq, tj, j, rg); break;
