@@ -153,13 +153,26 @@ __global__ __launch_bounds__(MAXT) void sweep_chunk_kernel(int n, int nb, int mo
             int mb = 0;
             for (; mb + HB <= cnt0; mb += HB) {  // full batches: no per-slot tests
                 if (mb + HB < cnt0) load_batch(mb + HB, hun, hvn);
+                // LDS operands buffered three slots ahead: their reads are in flight during the current slot's FMAs
+                double2 opu[4][SW_GROUP / 2], opv[4][SW_GROUP / 2];
+                auto load_ops = [&](int m, double2 (&ou)[SW_GROUP / 2], double2 (&ov)[SW_GROUP / 2]) {
+                    const double2 *ub = reinterpret_cast<const double2 *>(uit + m * KD + s0);
+                    const double2 *vb = reinterpret_cast<const double2 *>(vit + m * KD + s0);
+#pragma unroll
+                    for (int x = 0; x < SW_GROUP / 2; ++x) { ou[x] = ub[x]; ov[x] = vb[x]; }
+                };
+                load_ops(mb, opu[0], opv[0]);
+                load_ops(mb + 1, opu[1], opv[1]);
+                load_ops(mb + 2, opu[2], opv[2]);
 #pragma unroll
                 for (int k = 0; k < HB; ++k) {
-                    const double *ub = uit + (mb + k) * KD + s0, *vb = vit + (mb + k) * KD + s0;
+                    if (k + 3 < HB) load_ops(mb + k + 3, opu[(k + 3) & 3], opv[(k + 3) & 3]);
 #pragma unroll
-                    for (int q = 0; q < SW_GROUP; ++q) {
-                        colr[q] += hu[k] * vb[q];   // G[t, site_q] += U'[t][m] V[m][site_q]
-                        rowr[q] += ub[q] * hv[k];   // G[site_q, t] += U'[site_q][m] V[m][t]
+                    for (int x = 0; x < SW_GROUP / 2; ++x) {
+                        colr[2 * x] += hu[k] * opv[k & 3][x].x;       // G[t, site_q] += U'[t][m] V[m][site_q]
+                        colr[2 * x + 1] += hu[k] * opv[k & 3][x].y;
+                        rowr[2 * x] += opu[k & 3][x].x * hv[k];       // G[site_q, t] += U'[site_q][m] V[m][t]
+                        rowr[2 * x + 1] += opu[k & 3][x].y * hv[k];
                     }
                 }
 #pragma unroll
