@@ -98,7 +98,10 @@ __global__ __launch_bounds__(MAXT) void sweep_chunk_kernel(int n, int nb, int mo
     const int sl = t - site0;  // my index inside the chunk, if any
     // FULL: wave-uniform (the wave whose first row is site0), decided on a scalar
     const bool in_chunk = FULL ? (__builtin_amdgcn_readfirstlane(t) == site0) : (active && sl >= 0 && sl < nsites);
-    if (in_chunk) dg[b * KD + sl] = G[t + (long)n * t];
+    // the diagonal entry of my row (if it is one of the chunk's sites) is kept in a register: I am its only
+    // writer, the LDS copy is what the proposals of all threads read
+    double dgv = 0.0;
+    if (in_chunk) { dgv = G[t + (long)n * t]; dg[b * KD + sl] = dgv; }
     const WalkerRng rs = rngs[w];
     if (tid < KD) flip[tid] = 0;
     if (tid < nsites) {
@@ -251,7 +254,7 @@ __global__ __launch_bounds__(MAXT) void sweep_chunk_kernel(int n, int nb, int mo
                     if (in_chunk) {
                         uit[j * KD + sl] = newU;
                         vit[j * KD + sl] = newV;
-                        if (sl > s) dg[b * KD + sl] += newU * newV;  // sites <= s are done
+                        if (sl > s) { dgv += newU * newV; dg[b * KD + sl] = dgv; }  // sites <= s are done
                     }
                     // cs[s] itself must stay intact: waves drift apart between barriers (a rejected
                     // site has none) and a slower wave may not have read it yet for ITS proposal
