@@ -590,8 +590,13 @@ __device__ __forceinline__ double qc_apply(double (&x)[32], const double *vq, do
         const double y0 = x[k] - vv[k >> 1].x * wv, y1 = x[k + 1] - vv[k >> 1].y * wv;
         x[k] = y0;
         x[k + 1] = y1;
-        n0 += (rg + 8 * k > j ? 1.0 : 0.0) * (y0 * y0);
-        n1 += (rg + 8 * (k + 1) > j ? 1.0 : 0.0) * (y1 * y1);
+        if (k < KB0 + 4) {  // only the region's own 32 rows can be <= j
+            n0 += (rg + 8 * k > j ? 1.0 : 0.0) * (y0 * y0);
+            n1 += (rg + 8 * (k + 1) > j ? 1.0 : 0.0) * (y1 * y1);
+        } else {
+            n0 += y0 * y0;
+            n1 += y1 * y1;
+        }
     }
     return sum8(n0 + n1);
 }
@@ -658,6 +663,8 @@ __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double
     for (int j = 0; j < n; ++j) {
         const int par = j & 1;
         const unsigned tag = (unsigned)(epoch * 1024ull + (unsigned long long)j + 1ull);
+        // the column now at position j: read here, three barriers before thread 0 rewrites the table
+        const int cj = colat[j];
         // ---- my workgroup's best live column: larger norm first, then smaller position
         {
             const bool live = c < n && mypos >= j;
@@ -698,12 +705,23 @@ __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double
             const double pv = lbc >= 0 ? colbuf[tid] : 0.0;
             // header: packet 256 carries the norm, packet 258 {position, column id}; every word has the full tag
             const double meta = __longlong_as_double((long long)(unsigned)lbp | ((long long)(unsigned)lbc << 32));
+            // packet 262: element j of the candidate column, so that the reflector scalars do not have to wait
+            // for the column itself
+            const double pivot_elem = (tid == 0 && lbc >= 0) ? colbuf[j] : 0.0;
             if (same_xcd) {
                 qc_put_local(mb + 2 * tid, pv, tag, tag);
-                if (tid == 0) { qc_put_local(mb + 2 * 256, lbn, tag, tag); qc_put_local(mb + 2 * 258, meta, tag, tag); }
+                if (tid == 0) {
+                    qc_put_local(mb + 2 * 256, lbn, tag, tag);
+                    qc_put_local(mb + 2 * 258, meta, tag, tag);
+                    qc_put_local(mb + 2 * 262, pivot_elem, tag, tag);
+                }
             } else {
                 qc_put(mb + 2 * tid, pv, tag, tag);
-                if (tid == 0) { qc_put(mb + 2 * 256, lbn, tag, tag); qc_put(mb + 2 * 258, meta, tag, tag); }
+                if (tid == 0) {
+                    qc_put(mb + 2 * 256, lbn, tag, tag);
+                    qc_put(mb + 2 * 258, meta, tag, tag);
+                    qc_put(mb + 2 * 262, pivot_elem, tag, tag);
+                }
             }
         }
         // ---- collect: 16 lanes of wave 0 poll the 8 headers (lane l: packet 256 + 2 (l & 1) of part l >> 1) and
@@ -711,10 +729,12 @@ __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double
         // goes through LDS
         if (w == 0) {
             double hv = -1.0;
-            if (lane < 2 * QC_PARTS) {
+            if (lane < 3 * QC_PARTS) {  // lanes 0..15: norm / {pos, col} of part lane >> 1; lanes 16..23: its element j
                 unsigned hw;
-                const qc_word *mb = mb_unit + (long)(par * QC_PARTS + (lane >> 1)) * QC_MB * 2;
-                if (!qc_get(mb + 2 * (256 + 2 * (lane & 1)), tag, tag, 0xffffffffu, hv, hw)) s_abort = 1;
+                const int hp = lane < 2 * QC_PARTS ? (lane >> 1) : lane - 2 * QC_PARTS;
+                const int hk = lane < 2 * QC_PARTS ? 256 + 2 * (lane & 1) : 262;
+                const qc_word *mb = mb_unit + (long)(par * QC_PARTS + hp) * QC_MB * 2;
+                if (!qc_get(mb + 2 * hk, tag, tag, 0xffffffffu, hv, hw)) s_abort = 1;
             }
             // lane 2q holds the norm of part q, lane 2q+1 its {position, column}: give both to both lanes of the
             // pair, then reduce across the wave on DPP (largest norm, then smallest position; lanes >= 16 idle)
@@ -733,40 +753,40 @@ __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double
                 bestc = __builtin_amdgcn_readlane(qc, wl);
                 bestq = wl >> 1;
             }
+            const double best_xj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(hv), 2 * QC_PARTS + bestq),
+                                                    __builtin_amdgcn_readlane(__double2loint(hv), 2 * QC_PARTS + bestq));
             if (lane == 0) {
                 win[0] = bestn;
                 win[1] = __longlong_as_double((long long)bestp | ((long long)(unsigned)bestc << 32));
                 win[2] = (double)bestq;
+                win[3] = best_xj;
             }
         }
         __syncthreads();
-        // the column now at position j: read here, one barrier before thread 0 rewrites the table below
-        const int cj = colat[j];
-        double maxval;
+        double maxval, xi1;
         int jm, cm, wpart;
         {
             const double2 w01 = *reinterpret_cast<const double2 *>(win);
             const long long pc = __double_as_longlong(w01.y);
-            maxval = w01.x; jm = (int)(pc & 0x7fffffff); cm = (int)(pc >> 32); wpart = (int)win[2];
+            const double2 w23 = *reinterpret_cast<const double2 *>(win + 2);
+            maxval = w01.x; jm = (int)(pc & 0x7fffffff); cm = (int)(pc >> 32); wpart = (int)w23.x;
+            xi1 = w23.y;
         }
         if (cm < 0) { cm = cj; jm = j; maxval = 0.0; wpart = cm & 7; }  // nothing live: cannot happen for j < n
-        // ---- the winning column (tagged packets), reflector (UDT.jl:133-148), output column j
+        // ---- reflector scalars (UDT.jl:133-148) from the header alone; they overlap the column fetch below
+        // (branch-free: a zero column, maxval == 0, keeps tau = 0 and the column as it is)
+        const double rootn = sqrt(maxval);
+        const bool nz = maxval != 0.0;
+        const double nu = nz ? copysign(rootn, xi1) : 1.0;
+        const double xi = nz ? xi1 + nu : 1.0;
+        const double tj = nz ? xi / nu : 0.0;
+        // ---- the winning column (tagged packets), output column j
         double cv = 0.0;
         {
             unsigned hw;
             if (!qc_get(mb_unit + (long)(par * QC_PARTS + wpart) * QC_MB * 2 + 2 * tid, tag, tag, 0xffffffffu, cv, hw))
                 s_abort = 1;
         }
-        const double rootn = sqrt(maxval);  // overlaps the column load
-        colbuf[tid] = cv;
-        __syncthreads();
-        if (s_abort) break;
-        const double xi1 = colbuf[j];
-        // branch-free: a zero column (maxval == 0) keeps tau = 0 and the column as it is
-        const bool nz = maxval != 0.0;
-        const double nu = nz ? copysign(rootn, xi1) : 1.0;
-        const double xi = nz ? xi1 + nu : 1.0;
-        const double tj = nz ? xi / nu : 0.0;
         {
             const int r = tid;
             const double scaled = cv / xi;
@@ -787,6 +807,7 @@ __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double
             }
         }
         __syncthreads();
+        if (s_abort) break;
         // ---- apply H_j to my column if it is still live (reflectorApply!, UDT.jl:32-50); fresh norm
         if (c < n && mypos > j) {
             const double *vq = vperm + rg * QT_VS;
