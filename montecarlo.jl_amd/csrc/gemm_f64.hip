@@ -96,38 +96,56 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, int tiles_m, int 
         for (int j = 0; j < 2; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
 
     const int nk = (g.K + BK - 1) / BK;
-    double ra[4], rb[4];
+    // Register ring of two k-tiles: the loads of tile kt+2 are issued before the MFMAs of tile kt, so a tile
+    // has two iterations to arrive (with 32 units the grid gives each CU only two workgroups, and one
+    // iteration of MFMA work is shorter than an L2 round trip).
+    double ra[2][4], rb[2][4];
+    // The k-scaling (B_l = eT2 Diagonal(eV_l), ...) is applied when a tile goes to LDS, not when it is requested:
+    // multiplying at load time would wait for the tile (and for the HS-field byte behind the factor) right away
+    // and serialise the prefetch.  Until then the raw source of the factor sits in a register: the double of an
+    // array-type VecSrc or the Int8 spin of the conf-derived one (TA: four consecutive k per thread, else one).
+    constexpr int NKS = TA ? 4 : 1;
+    double ksd[2][NKS];
+    int ksc[2][NKS];
+    const int ksmode = g.kscale.mode;
+    const int kw = unit / g.nb, kblk = unit - kw * g.nb;
 
-    auto load = [&](int kt) {
+    auto load = [&](int kt, double (&qa)[4], double (&qb)[4], double (&qd)[NKS], int (&qc)[NKS]) {
         const int k0 = kt * BK;
-        tile_load<TA>(A, g.A.ld, m0, g.M, k0, g.K, tid, ra);
-        tile_load<!TB>(B, g.B.ld, n0, g.N, k0, g.K, tid, rb);
-        if (g.kscale.mode != 0) {
-            if (!TA) {
-                const int kk = k0 + (tid >> 4);
-                const double s = kk < g.K ? vs_get(g.kscale, unit, g.nb, kk) : 0.0;
+        tile_load<TA>(A, g.A.ld, m0, g.M, k0, g.K, tid, qa);
+        tile_load<!TB>(B, g.B.ld, n0, g.N, k0, g.K, tid, qb);
+        if (ksmode != 0) {
+            const int kb = TA ? k0 + ((tid & 3) << 2) : k0 + (tid >> 4);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) ra[i] *= s;
-            } else {
-                const int kk = k0 + ((tid & 3) << 2);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    ra[i] *= (kk + i < g.K) ? vs_get(g.kscale, unit, g.nb, kk + i) : 0.0;
+            for (int i = 0; i < NKS; ++i) {
+                const int kk = min(kb + i, g.K - 1);  // clamped: rows past K hold zeros in the tile anyway
+                if (ksmode == 2) qc[i] = g.kscale.conf[(long)kw * g.kscale.conf_stride + kk];
+                else qd[i] = g.kscale.d[(long)unit * g.kscale.stride + kk];
             }
         }
     };
-    auto store = [&](int buf) {
-        tile_store<TA>(As[buf], tid, ra);
-        tile_store<!TB>(Bs[buf], tid, rb);
+    auto ksfactor = [&](double d, int c) -> double {
+        if (ksmode == 2) return c > 0 ? g.kscale.cpos[kblk] : g.kscale.cneg[kblk];
+        if (ksmode == 1) return d;
+        if (ksmode == 3) return 1.0 / d;
+        if (ksmode == 4) return fmin(1.0, d);
+        return 1.0 / fmax(1.0, d);
     };
-
-    load(0);
-    store(0);
-    __syncthreads();
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) load(kt + 1);
+    auto store = [&](int buf, double (&qa)[4], const double (&qb)[4], const double (&qd)[NKS], const int (&qc)[NKS]) {
+        if (ksmode != 0) {
+            if (!TA) {
+                const double sc = ksfactor(qd[0], qc[0]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) qa[i] *= sc;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) qa[i] *= ksfactor(qd[i], qc[i]);
+            }
+        }
+        tile_store<TA>(As[buf], tid, qa);
+        tile_store<!TB>(Bs[buf], tid, qb);
+    };
+    auto compute = [&](int cur) {
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 4) {
             const int kq = kk + lq;
@@ -138,7 +156,23 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, int tiles_m, int 
             acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a0, acc[0][1], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a1, acc[1][1], 0, 0, 0);
         }
-        if (kt + 1 < nk) store(cur ^ 1);
+    };
+
+    load(0, ra[0], rb[0], ksd[0], ksc[0]);
+    store(0, ra[0], rb[0], ksd[0], ksc[0]);
+    __syncthreads();
+    if (nk > 1) load(1, ra[1], rb[1], ksd[1], ksc[1]);
+    for (int kt = 0; kt < nk; kt += 2) {
+        // even tile kt: LDS buffer 0, its registers (slot 0) are free for tile kt+2
+        if (kt + 2 < nk) load(kt + 2, ra[0], rb[0], ksd[0], ksc[0]);
+        compute(0);
+        if (kt + 1 < nk) store(1, ra[1], rb[1], ksd[1], ksc[1]);
+        __syncthreads();
+        if (kt + 1 >= nk) break;
+        // odd tile kt+1: LDS buffer 1, slot 1 free for tile kt+3
+        if (kt + 3 < nk) load(kt + 3, ra[1], rb[1], ksd[1], ksc[1]);
+        compute(1);
+        if (kt + 2 < nk) store(0, ra[0], rb[0], ksd[0], ksc[0]);
         __syncthreads();
     }
 
