@@ -606,7 +606,9 @@ __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double
                                                      double *mailbox,
                                                      unsigned long long epoch, int *errflag, int force_sc1)
 {
-    __shared__ __attribute__((aligned(16))) double colbuf[256];   // my best column / the winning column
+    // my best column, permuted by row group like vperm: row r at (r & 7) * QT_VS + (r >> 3), so that an owner
+    // lane (rows rg + 8k) stores pairs of consecutive k with 16-byte writes
+    __shared__ __attribute__((aligned(16))) double colbuf[8 * QT_VS];
     __shared__ __attribute__((aligned(16))) double vperm[8 * QT_VS];
     __shared__ __attribute__((aligned(16))) double wc[4][2];   // per wave: {norm, bits(pos | col << 32)}
     __shared__ __attribute__((aligned(16))) double win[4];     // the step's pivot: {norm, bits(pos | col << 32), part, -}
@@ -694,20 +696,21 @@ __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double
         // ---- its owner lanes put the column into LDS
         if (lbc >= 0 && w == ((lbc >> 3) >> 3)) {
             if (cg == ((lbc >> 3) & 7)) {  // exec-masked: the other lane groups issue no LDS writes at all
+                double2 *dst = reinterpret_cast<double2 *>(colbuf + rg * QT_VS);
 #pragma unroll
-                for (int k = 0; k < 32; ++k) colbuf[rg + 8 * k] = x[k];
+                for (int k = 0; k < 32; k += 2) dst[k >> 1] = make_double2(x[k], x[k + 1]);
             }
         }
         __syncthreads();
         // ---- publish: raw column + header as tagged packets; nothing to wait for
         {
             qc_word *mb = mb_unit + (long)(par * QC_PARTS + part) * QC_MB * 2;
-            const double pv = lbc >= 0 ? colbuf[tid] : 0.0;
+            const double pv = lbc >= 0 ? colbuf[(tid & 7) * QT_VS + (tid >> 3)] : 0.0;
             // header: packet 256 carries the norm, packet 258 {position, column id}; every word has the full tag
             const double meta = __longlong_as_double((long long)(unsigned)lbp | ((long long)(unsigned)lbc << 32));
             // packet 262: element j of the candidate column, so that the reflector scalars do not have to wait
             // for the column itself
-            const double pivot_elem = (tid == 0 && lbc >= 0) ? colbuf[j] : 0.0;
+            const double pivot_elem = (tid == 0 && lbc >= 0) ? colbuf[(j & 7) * QT_VS + (j >> 3)] : 0.0;
             if (same_xcd) {
                 qc_put_local(mb + 2 * tid, pv, tag, tag);
                 if (tid == 0) {
@@ -877,14 +880,15 @@ hipError_t launch_qr_pivot(int n, int n_units, double *A, long strideA, double *
 }
 
 // D, V and T from the factored matrix (UDT.jl:268-306).  One workgroup per unit.
-__global__ __launch_bounds__(1024) void udt_finish_kernel(int n, double *__restrict__ Aall, long strideA,
-                                                         const int *__restrict__ pivall,
-                                                         double *__restrict__ Dall, long strideD,
-                                                         double *__restrict__ Vall, long strideV,
-                                                         double *__restrict__ Tall, long strideT, int apply_pivot)
+constexpr int UF_SPLIT = 8;  // workgroups per matrix (column slabs): 32 matrices alone would leave 7/8 of the chip idle
+__global__ __launch_bounds__(256) void udt_finish_kernel(int n, double *__restrict__ Aall, long strideA,
+                                                        const int *__restrict__ pivall,
+                                                        double *__restrict__ Dall, long strideD,
+                                                        double *__restrict__ Vall, long strideV,
+                                                        double *__restrict__ Tall, long strideT, int apply_pivot)
 {
     extern __shared__ __attribute__((aligned(16))) double dinv[];  // 1/D
-    const int unit = blockIdx.x;
+    const int unit = blockIdx.x / UF_SPLIT, slab = blockIdx.x % UF_SPLIT;
     double *__restrict__ A = Aall + (long)unit * strideA;
     double *__restrict__ D = Dall + (long)unit * strideD;
     const int *__restrict__ piv = pivall + (long)unit * n;
@@ -892,13 +896,13 @@ __global__ __launch_bounds__(1024) void udt_finish_kernel(int n, double *__restr
     double *__restrict__ T = Tall ? Tall + (long)unit * strideT : nullptr;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         const double d = fabs(A[i + (long)n * i]);
-        D[i] = d;
+        if (slab == 0) D[i] = d;
         dinv[i] = 1.0 / d;
     }
     __syncthreads();
     const int rpt = (n + 63) / 64;  // rows handled per lane
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    for (int c = wave; c < n; c += nw) {
+    for (int c = slab * nw + wave; c < n; c += nw * UF_SPLIT) {
         const int pc = apply_pivot ? piv[c] : c;
         for (int q = 0; q < rpt; ++q) {
             const int r = lane + 64 * q;
@@ -915,8 +919,8 @@ hipError_t launch_udt_finish(int n, int n_units, double *A, long strideA, const 
                              long strideD, double *V, long strideV, double *Tout, long strideT,
                              int apply_pivot, hipStream_t s)
 {
-    hipLaunchKernelGGL(udt_finish_kernel, dim3(n_units), dim3(1024), n * sizeof(double), s, n, A, strideA, pivot,
-                       D, strideD, V, strideV, Tout, strideT, apply_pivot);
+    hipLaunchKernelGGL(udt_finish_kernel, dim3(n_units * UF_SPLIT), dim3(256), n * sizeof(double), s, n, A, strideA,
+                       pivot, D, strideD, V, strideV, Tout, strideT, apply_pivot);
     return hipGetLastError();
 }
 
