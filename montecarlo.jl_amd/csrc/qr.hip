@@ -862,8 +862,7 @@ hipError_t launch_qr_pivot(int n, int n_units, double *A, long strideA, double *
                                       (int)lds_t);
             attr_set = true;
         }
-        static const char *dbg = getenv("DQMC_QR_STEPS");
-        const int nsteps = dbg ? (atoi(dbg) < n ? atoi(dbg) : n) : n;
+        const int nsteps = n;
         hipLaunchKernelGGL(qr_tile256_kernel, dim3(n_units), dim3(QT_THREADS), lds_t, s, n, nsteps, A, strideA, tau, pivot);
         return hipGetLastError();
     }
