@@ -1052,11 +1052,14 @@ __global__ __launch_bounds__(128) void trsm_mfma_kernel(int n, const double *__r
         // k < j0 <= col, the substitution rows j0 + c2 < col), indices are clamped into the matrix, and
         // the number of 8-row steps is wave-uniform
         const int j0 = J << 4, c = tid >> 3, col = min(j0 + c, n - 1);
-        const int steps = J < nblk ? (min(j0 + 16, n) + 7) >> 3 : 0;
+        const int steps = J < nblk ? ((min(j0 + 16, n) + 15) >> 4) << 1 : 0;  // 8-row steps, rounded up to a pair
         const double *__restrict__ tc = T + (long)n * col;
 #pragma unroll
-        for (int i = 0; i < 32; ++i) {
-            if (i < steps) pre[i] = tc[min((tid & 7) + 8 * i, n - 1)];
+        for (int i = 0; i < 32; i += 2) {
+            if (i < steps) {  // one wave-uniform guard per pair
+                pre[i] = tc[min((tid & 7) + 8 * i, n - 1)];
+                pre[i + 1] = tc[min((tid & 7) + 8 * (i + 1), n - 1)];
+            }
         }
         if (J < nblk) {
             pre_w[0] = Wu[(long)J * 256 + tid];
@@ -1068,10 +1071,13 @@ __global__ __launch_bounds__(128) void trsm_mfma_kernel(int n, const double *__r
         const int j0 = J << 4;
         __syncthreads();  // previous block's panel no longer read; first pass: Xs complete
         {
-            const int c = tid >> 3, steps = (min(j0 + 16, n) + 7) >> 3;  // as fetched: wave-uniform
+            const int c = tid >> 3, steps = ((min(j0 + 16, n) + 15) >> 4) << 1;  // as fetched: wave-uniform
 #pragma unroll
-            for (int i = 0; i < 32; ++i) {
-                if (i < steps) Tp[c * TM_TS + (tid & 7) + 8 * i] = pre[i];
+            for (int i = 0; i < 32; i += 2) {
+                if (i < steps) {
+                    Tp[c * TM_TS + (tid & 7) + 8 * i] = pre[i];
+                    Tp[c * TM_TS + (tid & 7) + 8 * (i + 1)] = pre[i + 1];
+                }
             }
             Wl[(tid >> 4) * 18 + (tid & 15)] = pre_w[0];
             Wl[((tid + 128) >> 4) * 18 + (tid & 15)] = pre_w[1];
