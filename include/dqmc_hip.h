@@ -248,7 +248,8 @@ int dqmc_calculate_greens(int32_t device_id, int32_t n, int32_t batch, const dou
 /* ---- instrumentation ------------------------------------------------------ */
 /* Per-kernel-family device time accumulated with HIP events on the handle's
  * stream when enabled (off by default; used by bench.py's roofline leg). */
-enum { DQMC_K_GEMM = 0, DQMC_K_QR = 1, DQMC_K_TRSM = 2, DQMC_K_SWEEP = 3, DQMC_K_MISC = 4, DQMC_K_COUNT = 5 };
+enum { DQMC_K_GEMM = 0, DQMC_K_QR = 1, DQMC_K_TRSM = 2, DQMC_K_SWEEP = 3, DQMC_K_MISC = 4, DQMC_K_FLUSH = 5,
+       DQMC_K_COUNT = 6 };
 int dqmc_timing_enable(dqmc_handle *h, int32_t on);
 int dqmc_timing_get(dqmc_handle *h, double *ms /* DQMC_K_COUNT */, int64_t *launches /* DQMC_K_COUNT */);
 /* fp64 MFMA micro-benchmark: issues `iters` dependent-free v_mfma_f64_16x16x4_f64

@@ -12,7 +12,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "dqmc_hip.h")
 
 OK, ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_STATE, ERR_RNG = 0, -1, -2, -3, -4, -5
 ATTRACTIVE, REPULSIVE = 0, 1
-K_FAMILIES = ("gemm", "qr", "trsm", "sweep", "misc")
+K_FAMILIES = ("gemm", "qr", "trsm", "sweep", "misc", "flush")
 
 
 class DQMCError(RuntimeError):

@@ -9,6 +9,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -41,6 +42,8 @@ struct dqmc_handle {
     double *Dl = nullptr, *Dr = nullptr, *tau = nullptr;
     int *pivot = nullptr;
     double *sU = nullptr, *sVT = nullptr;
+    double *greens_alt = nullptr, *lu_img = nullptr;  // decide / apply sweep (sweep_lu.hip)
+    bool sweep_lu = true;
     WalkerRng *rng = nullptr;
     DevStats *stats = nullptr;
     std::vector<double *> uniforms;  // per walker device arrays
@@ -169,6 +172,27 @@ static GemmArgs gemm_base(dqmc_handle *h, MatRef A, int tA, MatRef B, int tB, do
 }
 static MatRef U_(dqmc_handle *h, const double *p) { return mat(p, h->nn, h->n); }        // per unit
 static MatRef C_(dqmc_handle *h, const double *p) { return mat(p, 0, h->n, h->nn); }     // shared constant, per block
+// a pair of events for a dispatch-attached (kernel-only) timing, or nulls when timing is off
+static void timing_events(dqmc_handle *h, hipEvent_t *a, hipEvent_t *b)
+{
+    *a = *b = nullptr;
+    if (!h->timing) return;
+    auto get = [&]() {
+        hipEvent_t e;
+        if (!h->pool.empty()) { e = h->pool.back(); h->pool.pop_back(); }
+        else (void)hipEventCreate(&e);
+        return e;
+    };
+    *a = get();
+    *b = get();
+}
+static int timing_push(dqmc_handle *h, hipEvent_t a, hipEvent_t b, int fam)
+{
+    if (!a) return 0;
+    h->pending.push_back({a, b, fam});
+    if (h->pending.size() >= 2048) return timing_drain(h);
+    return 0;
+}
 static int run_gemm(dqmc_handle *h, const GemmArgs &g)
 {
     if (!h->timing) {
@@ -487,6 +511,24 @@ static int sweep_spatial(dqmc_handle *h)
     if (l < 1 || l > h->M) return fail(h, DQMC_ERR_STATE, "sweep_spatial: current_slice outside 1..slices");
     int8_t *cslice = h->conf + (long)(l - 1) * h->N;
     h->conf_version++;
+    if (h->sweep_lu) {
+        // decide on the 64 x 64 block (one wave per walker), then apply the chunk out of place with MFMA
+        double *cur = h->greens, *alt = h->greens_alt;
+        for (int site0 = 0; site0 < h->N; site0 += 64) {
+            const int ns = std::min(64, h->N - site0);
+            hipEvent_t a, b;
+            timing_events(h, &a, &b);
+            HIPCHK(launch_sweep_lu(h->n, h->nb, h->W, cur, h->nn, cslice, (long)h->N * h->M, site0, ns, h->lu_img, h->sc,
+                                   h->rng, h->stats, h->p.check_sign_problem, h->stream, a, b));
+            CHK(timing_push(h, a, b, DQMC_K_SWEEP));
+            timing_events(h, &a, &b);
+            HIPCHK(launch_sweep_flush_lu(h->n, h->units, cur, alt, h->nn, site0, ns, h->lu_img, h->stream, a, b));
+            CHK(timing_push(h, a, b, DQMC_K_FLUSH));
+            std::swap(cur, alt);
+        }
+        if (cur != h->greens) std::swap(h->greens, h->greens_alt);
+        return 0;
+    }
     for (int site0 = 0; site0 < h->N; site0 += h->kd) {
         const int ns = std::min(h->kd, h->N - site0);
         {
@@ -550,8 +592,10 @@ int dqmc_create(const dqmc_params *p, dqmc_handle **out)
         return fail(nullptr, DQMC_ERR_INVALID, "dqmc_create: hopping exponentials missing");
     if (!(p->U >= 0.0)) return fail(nullptr, DQMC_ERR_INVALID, "dqmc_create: U must be positive");
     const int nb = p->model_kind == DQMC_REPULSIVE ? 2 : 1;
-    if (nb * ((p->n_sites + 63) & ~63) > 1024 || p->n_sites > 1024)
-        return fail(nullptr, DQMC_ERR_INVALID, "dqmc_create: n_blocks * n_sites exceeds 1024 (unsupported)");
+    const bool sweep_old = getenv("DQMC_SWEEP_OLD") != nullptr;  // one-workgroup-per-walker chunk kernel (A/B only)
+    if (p->n_sites > 1024) return fail(nullptr, DQMC_ERR_INVALID, "dqmc_create: n_sites exceeds 1024 (unsupported)");
+    if (sweep_old && nb * ((p->n_sites + 63) & ~63) > 1024)
+        return fail(nullptr, DQMC_ERR_INVALID, "dqmc_create: DQMC_SWEEP_OLD needs n_blocks * n_sites <= 1024");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(nullptr, DQMC_ERR_NO_DEVICE, "dqmc_create: no HIP device visible");
@@ -570,6 +614,7 @@ int dqmc_create(const dqmc_params *p, dqmc_handle **out)
     h->units = h->W * h->nb;
     h->nn = (long)h->n * h->n;
     h->kd = sweep_kd(h->n, h->nb);
+    h->sweep_lu = !sweep_old;
     // lambda = acosh(exp(U*dtau/2)) (Attractive.jl:103,118; Repulsive.jl:116,138)
     h->lambda = std::acosh(std::exp(0.5 * p->U * p->delta_tau));
     h->epl = std::exp(h->lambda);
@@ -626,6 +671,8 @@ int dqmc_create(const dqmc_params *p, dqmc_handle **out)
     CCHK(alloc_qr_workspace(h));
     CCHK(dalloc(h, &h->sU, (size_t)h->units * h->n * h->kd));
     CCHK(dalloc(h, &h->sVT, (size_t)h->units * h->n * h->kd));
+    CCHK(dalloc(h, &h->greens_alt, un));
+    CCHK(dalloc(h, &h->lu_img, (size_t)h->units * sweep_lu_image_doubles()));
     CCHK(dalloc(h, &h->rng, (size_t)h->W));
     CCHK(dalloc(h, &h->stats, (size_t)h->W));
     {

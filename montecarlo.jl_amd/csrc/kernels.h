@@ -126,11 +126,54 @@ struct DevStats {
     long long prop_local, acc_local;
     DevMagStats negative_probability, propagation_error;
 };
+#ifdef __HIPCC__
+__device__ __forceinline__ double philox_uniform(unsigned long long seed, unsigned long long index)
+{
+    unsigned int c0 = (unsigned int)index, c1 = (unsigned int)(index >> 32), c2 = 0u, c3 = 0u;
+    unsigned int k0 = (unsigned int)seed, k1 = (unsigned int)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
+        const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned int n0 = (unsigned int)(p1 >> 32) ^ c1 ^ k0;
+        const unsigned int n1 = (unsigned int)p1;
+        const unsigned int n2 = (unsigned int)(p0 >> 32) ^ c3 ^ k1;
+        const unsigned int n3 = (unsigned int)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    const unsigned long long hi = c0 >> 5, lo = c1 >> 6;
+    return (double)((hi << 26) | lo) * (1.0 / 9007199254740992.0);
+}
+
+__device__ __forceinline__ void magstats_push(DevMagStats &s, double value)
+{
+    const double v = log10(fabs(value));
+    s.max = fmax(s.max, v);
+    s.min = fmin(s.min, v);
+    s.sum += v;
+    s.count += 1;
+}
+#endif
 int sweep_kd(int n, int nb);  // chunk length (update slots per flush) for this problem size
 hipError_t launch_sweep_chunk(int n, int nb, int n_walkers, int model, double *G, long strideG,
                               int8_t *conf_slice, long conf_stride, int site0, int nsites,
                               double *Uout, double *VTout, long strideUV, SweepConsts sc,
                               WalkerRng *rng, DevStats *stats, int check_sign, hipStream_t s);
+
+// The same chunk as a decide / apply pair (sweep_lu.hip): sweep_lu_kernel eliminates the 64 x 64 block G[c, c]
+// with one wave per walker (decisions, HS field, counters) and leaves register images of the triangular factors
+// (sweep_lu_image_doubles() doubles per unit); sweep_flush_lu_kernel applies the chunk to G out of place
+// (Gout = Gin + T R0).  No limit on n_blocks * n_sites.
+size_t sweep_lu_image_doubles();
+hipError_t launch_sweep_lu(int n, int nb, int n_walkers, const double *G, long strideG, int8_t *conf_slice,
+                           long conf_stride, int site0, int nsites, double *img, SweepConsts sc, WalkerRng *rng,
+                           DevStats *stats, int check_sign, hipStream_t s, hipEvent_t start = nullptr,
+                           hipEvent_t stop = nullptr);
+hipError_t launch_sweep_flush_lu(int n, int n_units, const double *Gin, double *Gout, long strideG, int site0,
+                                 int nsites, const double *img, hipStream_t s, hipEvent_t start = nullptr,
+                                 hipEvent_t stop = nullptr);
 
 // small helpers
 hipError_t launch_set_identity(int n, int count, double *A, long stride, hipStream_t s);

@@ -15,35 +15,6 @@
 
 namespace dqmc {
 
-__device__ __forceinline__ double philox_uniform(unsigned long long seed, unsigned long long index)
-{
-    unsigned int c0 = (unsigned int)index, c1 = (unsigned int)(index >> 32), c2 = 0u, c3 = 0u;
-    unsigned int k0 = (unsigned int)seed, k1 = (unsigned int)(seed >> 32);
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
-        const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
-        const unsigned int n0 = (unsigned int)(p1 >> 32) ^ c1 ^ k0;
-        const unsigned int n1 = (unsigned int)p1;
-        const unsigned int n2 = (unsigned int)(p0 >> 32) ^ c3 ^ k1;
-        const unsigned int n3 = (unsigned int)p0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-    const unsigned long long hi = c0 >> 5, lo = c1 >> 6;
-    return (double)((hi << 26) | lo) * (1.0 / 9007199254740992.0);
-}
-
-__device__ __forceinline__ void magstats_push(DevMagStats &s, double value)
-{
-    const double v = log10(fabs(value));
-    s.max = fmax(s.max, v);
-    s.min = fmin(s.min, v);
-    s.sum += v;
-    s.count += 1;
-}
-
 constexpr int SW_GROUP = 8;   // sites per group (static register indices inside a group)
 constexpr int SW_KD = 64;     // sites per chunk = update slots per flush
 

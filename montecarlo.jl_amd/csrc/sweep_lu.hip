@@ -1,0 +1,409 @@
+// sweep_lu.hip — sweep_spatial (src/flavors/DQMC/DQMC.jl:546-582) with propose_local /
+// accept_local! of HubbardModelAttractive.jl:113-155 and HubbardModelRepulsive.jl:128-232 as a
+// "decide on the 64 x 64 block, apply with MFMA" pair of kernels per chunk of 64 sites.
+//
+// Within a chunk c of 64 consecutive sites the Metropolis decisions only ever look at the diagonal of
+// S = G[c, c], and an accepted flip at site s changes the later part of that block by the rank-1 term
+//     S[k, l] += x_s S[k, s] S[s, l]      (k, l > s;  x_s = gamma / (1 + gamma (1 - S[s, s])))
+// (accept_local!'s  G -= (e_i - G[:, i]) x G[i, :]  restricted to the chunk).  The sequential part is
+// therefore a conditional LU-type elimination of a 64 x 64 matrix:
+//
+//   sweep_lu_kernel      one wave per walker.  S and S' live in MFMA accumulator layout (16 x 16 tiles of
+//                        v_mfma_f64_16x16x4_f64), so that row s of S / of S' is at the same time the B operand
+//                        (the row G[s, :]) and the A operand (the column G[:, s]) of the rank-1 update: no data
+//                        moves between lanes, the diagonal entry is read with v_readlane.  Tiles of the current
+//                        block row are updated at every accepted site, the remaining ones once per panel of four
+//                        sites with a full k = 4 MFMA.  By-products: the unit-triangular inverses of the 16 x 16
+//                        diagonal blocks (one more MFMA per site each).
+//   sweep_flush_lu_kernel  G_out = G_in + T R0,  R0 = G_in[c, :],  T = (G_in[:, c] - E) X (I - Uu X)^-1 (I - L X)^-1
+//                        with Uu / L the strict upper / lower parts of the eliminated block and X = diag(x): two
+//                        block-triangular solves per 16 columns of T' (MFMA, operands of the triangles straight
+//                        from the first kernel's register images) and the K = 64 update of a 64 x 64 tile of G.
+//
+// This is a re-association of the reference's arithmetic only (the literal algorithm is restated in
+// tools/proto/lu_sweep_proto.py and in the oracle).
+#include "kernels.h"
+#include <hip/hip_ext.h>
+
+namespace dqmc {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// per-unit image written by sweep_lu_kernel, read by sweep_flush_lu_kernel (doubles):
+//   [U pair tiles 6][L pair tiles 6][PT 4][Q 4] each 4 regs x 64 lanes, then x[64]
+constexpr int LU_TILE = 256;
+constexpr int LU_OFF_U = 0, LU_OFF_L = 6 * LU_TILE, LU_OFF_PT = 12 * LU_TILE, LU_OFF_Q = 16 * LU_TILE;
+constexpr int LU_IMG = 20 * LU_TILE;
+constexpr int LU_STRIDE = LU_IMG + 64;
+__host__ __device__ constexpr int lu_pair(int K, int J)  // K < J: (0,1) (0,2) (0,3) (1,2) (1,3) (2,3)
+{
+    return K == 0 ? J - 1 : (K == 1 ? J + 1 : 5);
+}
+size_t sweep_lu_image_doubles() { return LU_STRIDE; }
+
+__device__ __forceinline__ double readlane_d(double v, int lane)
+{
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(u & 0xffffffffull), lane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(u >> 32), lane);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+
+// Accumulator layout of v_mfma_f64_16x16x4_f64: register r of lane l = (g = l >> 4, ci = l & 15) holds element
+// [4 r + g][ci] of a 16 x 16 tile; the A operand is A[i = ci][k = g], the B operand B[k = g][j = ci].
+// S[I][J] (J >= I): tile of S, rows 16 I.., columns 16 J..;  ST[I][J]: tile of S', i.e. ST[I][J][rho][kappa] =
+// S[16 J + kappa][16 I + rho].  Only the upper block triangle of both is kept.
+template <int NB, bool FULL>
+__global__ __launch_bounds__(64) void sweep_lu_kernel(int n, const double *__restrict__ Gall, long strideG,
+                                                     int8_t *__restrict__ conf_slice, long conf_stride, int site0,
+                                                     int nsites, double *__restrict__ img_all, SweepConsts sc,
+                                                     WalkerRng *rngs, DevStats *stats, int check_sign)
+{
+    const int w = blockIdx.x, lane = threadIdx.x, g = lane >> 4, ci = lane & 15;
+    int8_t *__restrict__ cw = conf_slice + (long)w * conf_stride;
+    const int myc = (FULL || lane < nsites) ? (int)cw[site0 + (FULL ? lane : min(lane, nsites - 1))] : 1;
+    const unsigned long long cbits = __ballot(myc > 0);
+    const WalkerRng rs = rngs[w];
+    double uvec;  // lane k: the k-th uniform this chunk consumes, whichever site consumes it (DQMC.jl:573)
+    {
+        const unsigned long long d = rs.draw + (unsigned long long)lane;
+        uvec = rs.uniforms ? (d < rs.n_uniforms ? rs.uniforms[d] : 2.0) : philox_uniform(rs.seed, d);
+    }
+
+    d4 S[NB][4][4], ST[NB][4][4];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const double *__restrict__ G = Gall + (long)(w * NB + b) * strideG + (long)site0 * n + site0;
+#pragma unroll
+        for (int I = 0; I < 4; ++I)
+#pragma unroll
+            for (int J = I; J < 4; ++J)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rho = 16 * I + 4 * r + g, kap = 16 * J + ci;  // S[rho][kap]; ST: S[kap][rho]
+                    if (FULL) {
+                        S[b][I][J][r] = G[rho + (long)n * kap];
+                        ST[b][I][J][r] = G[kap + (long)n * rho];
+                    } else {  // clamped addresses, no per-lane branches; entries outside the chunk are zero
+                        const bool ok = rho < nsites && kap < nsites;
+                        const int rc = min(rho, nsites - 1), kc = min(kap, nsites - 1);
+                        const double a = G[rc + (long)n * kc], c = G[kc + (long)n * rc];
+                        S[b][I][J][r] = ok ? a : 0.0;
+                        ST[b][I][J][r] = ok ? c : 0.0;
+                    }
+                }
+    }
+
+    const double g0 = sc.gamma[0], g1 = sc.gamma[1], e0 = sc.ebos[0], e1 = sc.ebos[1];
+    const double du0 = sc.dup[0], du1 = sc.dup[1], dd0 = sc.ddn[0], dd1 = sc.ddn[1];
+    unsigned long long accbits = 0ull, negbits = 0ull;
+    int ndraw = 0, exhausted = 0;
+    double xall[NB], negv = 0.0;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) xall[b] = 0.0;
+
+#pragma unroll
+    for (int I0 = 0; I0 < 4; ++I0) {
+        if (!FULL && 16 * I0 >= nsites) break;
+        d4 PT[NB], Q[NB];  // ((I - X Uu)^-1)' and (I - L X)^-1 of this diagonal block
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) PT[b][r] = Q[b][r] = (4 * r + g == ci) ? 1.0 : 0.0;
+#pragma unroll
+        for (int r0 = 0; r0 < 4; ++r0) {
+            double xv4[NB];  // lane group k: x of site 16 I0 + 4 r0 + k (0 if rejected)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) xv4[b] = 0.0;
+            unsigned panel_acc = 0;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int c = 4 * r0 + ks, s = 16 * I0 + c;
+                if (!FULL && s >= nsites) continue;
+                const int src = 16 * ks + c;  // the lane that holds S[s][s] in register r0 of the diagonal tile
+                const int spin = (int)((cbits >> s) & 1ull);
+                double det, p, xb[NB];
+                if (NB == 1) {  // HubbardModelAttractive.jl:113-127
+                    const double d0 = readlane_d(S[0][I0][I0][r0], src);
+                    const double gamma = spin ? g1 : g0;
+                    const double r = 1.0 + gamma * (1.0 - d0);
+                    det = r * r;
+                    p = (spin ? e1 : e0) * det;
+                    xb[0] = gamma / r;  // Attractive.jl:149: x = gamma / (1 + gamma * IG[i])
+                } else {        // HubbardModelRepulsive.jl:128-156,174-191
+                    const double d0 = readlane_d(S[0][I0][I0][r0], src);
+                    const double d1 = readlane_d(S[NB - 1][I0][I0][r0], src);
+                    const double D0 = spin ? du1 : du0, D1 = spin ? dd1 : dd0;
+                    const double R0 = 1.0 + D0 * (1.0 - d0), R1 = 1.0 + D1 * (1.0 - d1);
+                    det = R0 * R1;
+                    p = det;
+                    const double inv_div = 1.0 / det;
+                    xb[0] = (R1 * inv_div) * D0;
+                    xb[NB - 1] = (R0 * inv_div) * D1;
+                    if (check_sign && det < 0.0) {
+                        negbits |= 1ull << s;
+                        negv = lane == s ? det : negv;
+                    }
+                }
+                bool acc;
+                if (p > 1.0) acc = true;  // DQMC.jl:573: rand() is consumed only when p <= 1
+                else {
+                    const double u = readlane_d(uvec, ndraw);
+                    ++ndraw;
+                    if (u == 2.0) exhausted = 1;
+                    acc = u < p;
+                }
+                if (__builtin_amdgcn_readfirstlane((int)acc)) {
+                    accbits |= 1ull << s;
+                    panel_acc |= 1u << ks;
+                    const bool lm = g == ks, lm2 = lm && ci > c;
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) {
+                        const double x = xb[b];
+                        xall[b] = lane == s ? x : xall[b];
+                        xv4[b] = lm ? x : xv4[b];
+                        const double mS = lm2 ? S[b][I0][I0][r0] : 0.0;    // G[s, later columns of the block]
+                        const double mT = lm2 ? ST[b][I0][I0][r0] : 0.0;   // G[later rows of the block, s]
+                        const double aS = x * mT, aT = x * mS;
+                        S[b][I0][I0] = MFMA(aS, mS, S[b][I0][I0]);
+                        ST[b][I0][I0] = MFMA(aT, mT, ST[b][I0][I0]);
+#pragma unroll
+                        for (int J = I0 + 1; J < 4; ++J) {
+                            const double bS = lm ? S[b][I0][J][r0] : 0.0, bT = lm ? ST[b][I0][J][r0] : 0.0;
+                            S[b][I0][J] = MFMA(aS, bS, S[b][I0][J]);
+                            ST[b][I0][J] = MFMA(aT, bT, ST[b][I0][J]);
+                        }
+                        PT[b] = MFMA(aT, lm ? PT[b][r0] : 0.0, PT[b]);  // PT[j][:] += x G[s, j] PT[s][:]
+                        Q[b] = MFMA(aS, lm ? Q[b][r0] : 0.0, Q[b]);     // Q[k][:]  += x G[k, s] Q[s][:]
+                    }
+                }
+            }
+            // the four sites of the panel applied to the later block rows with full k = 4 MFMAs
+            if (I0 < 3 && panel_acc != 0) {
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+#pragma unroll
+                    for (int I = I0 + 1; I < 4; ++I) {
+                        const double aFS = xv4[b] * ST[b][I0][I][r0], aFT = xv4[b] * S[b][I0][I][r0];
+#pragma unroll
+                        for (int J = I; J < 4; ++J) {
+                            S[b][I][J] = MFMA(aFS, S[b][I0][J][r0], S[b][I][J]);
+                            ST[b][I][J] = MFMA(aFT, ST[b][I0][J][r0], ST[b][I][J]);
+                        }
+                    }
+            }
+        }
+        // block row I0 is final: register images for the flush kernel
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            double *__restrict__ img = img_all + (long)(w * NB + b) * LU_STRIDE;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                // element [4 r + g][ci] goes to A-operand position (i = 4 r + g, k = ci) of the transposed tile
+                const int tpos = (ci >> 2) * 64 + 16 * (ci & 3) + 4 * r + g;
+#pragma unroll
+                for (int J = I0 + 1; J < 4; ++J) {
+                    img[LU_OFF_U + lu_pair(I0, J) * LU_TILE + r * 64 + lane] = S[b][I0][J][r];
+                    img[LU_OFF_L + lu_pair(I0, J) * LU_TILE + tpos] = ST[b][I0][J][r];
+                }
+                img[LU_OFF_PT + I0 * LU_TILE + tpos] = PT[b][r];
+                img[LU_OFF_Q + I0 * LU_TILE + r * 64 + lane] = Q[b][r];
+            }
+        }
+    }
+    if (!FULL) {  // blocks past the end of a short chunk: identity triangles
+        for (int I0 = (nsites + 15) / 16; I0 < 4; ++I0)
+            for (int b = 0; b < NB; ++b) {
+                double *__restrict__ img = img_all + (long)(w * NB + b) * LU_STRIDE;
+                for (int r = 0; r < 4; ++r) {
+                    const double idv = (4 * r + g == ci) ? 1.0 : 0.0;
+                    for (int J = I0 + 1; J < 4; ++J) {
+                        img[LU_OFF_U + lu_pair(I0, J) * LU_TILE + r * 64 + lane] = 0.0;
+                        img[LU_OFF_L + lu_pair(I0, J) * LU_TILE + r * 64 + lane] = 0.0;
+                    }
+                    img[LU_OFF_PT + I0 * LU_TILE + r * 64 + lane] = idv;
+                    img[LU_OFF_Q + I0 * LU_TILE + r * 64 + lane] = idv;
+                }
+            }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) img_all[(long)(w * NB + b) * LU_STRIDE + LU_IMG + lane] = xall[b];
+    if (lane < nsites && ((accbits >> lane) & 1ull)) cw[site0 + lane] = (int8_t)(-myc);
+    if (lane == 0) {
+        rngs[w].draw = rs.draw + (unsigned long long)ndraw;
+        if (exhausted) rngs[w].exhausted = 1;
+        stats[w].prop_local += nsites;
+        stats[w].acc_local += __popcll(accbits);
+    }
+    if (NB == 2 && negbits != 0ull) {  // sign-problem statistics in site order (DQMC.jl:560-566)
+        for (int s = 0; s < nsites; ++s)
+            if ((negbits >> s) & 1ull) {
+                const double v = readlane_d(negv, s);
+                if (lane == 0) magstats_push(stats[w].negative_probability, v);
+            }
+    }
+}
+
+hipError_t launch_sweep_lu(int n, int nb, int n_walkers, const double *G, long strideG, int8_t *conf_slice,
+                           long conf_stride, int site0, int nsites, double *img, SweepConsts sc, WalkerRng *rng,
+                           DevStats *stats, int check_sign, hipStream_t s, hipEvent_t start, hipEvent_t stop)
+{
+    if (nsites < 1 || nsites > 64 || site0 < 0 || site0 + nsites > n || nb < 1 || nb > 2) return hipErrorInvalidValue;
+    dim3 grid(n_walkers), block(64);
+    const bool full = nsites == 64;
+#define LU_LAUNCH(NBV, FL)                                                                                        \
+    hipExtLaunchKernelGGL((sweep_lu_kernel<NBV, FL>), grid, block, 0, s, start, stop, 0, n, G, strideG, conf_slice, \
+                          conf_stride, site0, nsites, img, sc, rng, stats, check_sign)
+    if (nb == 1) { if (full) LU_LAUNCH(1, true); else LU_LAUNCH(1, false); }
+    else { if (full) LU_LAUNCH(2, true); else LU_LAUNCH(2, false); }
+#undef LU_LAUNCH
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// G_out[t][t'] = G_in[t][t'] + sum_s T'[s][t] G_in[site0 + s][t'] for one 64 x 64 tile; wave w owns the 16 rows
+// t = m0 + 16 w .. and computes T' for them (two block-triangular solves, see the file header).
+constexpr int FL_LDR = 66;  // row stride of the R0 tile in LDS (doubles): ci * 66 + g hits 32 distinct 8-byte slots
+template <bool FULL>
+__global__ __launch_bounds__(256) void sweep_flush_lu_kernel(int n, int n_units, const double *__restrict__ Gin_all,
+                                                            double *__restrict__ Gout_all, long strideG, int site0,
+                                                            int nsites, const double *__restrict__ img_all,
+                                                            int tiles_m, int tiles_n)
+{
+    extern __shared__ __attribute__((aligned(16))) double fsm[];
+    double *img = fsm;                 // [LU_IMG + 64]
+    double *xs = fsm + LU_IMG;
+    double *Rl = fsm + LU_STRIDE;      // [64 t'][FL_LDR]: R0[s][t'] at Rl[t' * FL_LDR + s]
+    const int bid = blockIdx.x, xcd = bid & 7, seq = bid >> 3;
+    const int T = tiles_m * tiles_n;
+    const int unit = (seq / T) * 8 + xcd;
+    if (unit >= n_units) return;
+    const int tile = seq % T;
+    const int m0 = (tile % tiles_m) * 64, n0 = (tile / tiles_m) * 64;
+    const double *__restrict__ Gin = Gin_all + (long)unit * strideG;
+    double *__restrict__ Gout = Gout_all + (long)unit * strideG;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, ci = lane & 15;
+    const int t = m0 + 16 * wave + ci;             // my row of G (contiguous direction)
+    const int tq = FULL ? t : min(t, n - 1);
+
+    // the tile of G itself first (the kernel is bound by this read-modify-write)
+    d4 acc[4];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int tp = n0 + 16 * jt + 4 * r + g;
+            acc[jt][r] = Gin[tq + (long)n * (FULL ? tp : min(tp, n - 1))];
+        }
+    // C0'[s][t] = G_in[t][site0 + s] - delta
+    d4 az[4];
+#pragma unroll
+    for (int J = 0; J < 4; ++J)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int s = 16 * J + 4 * r + g;
+            const int col = site0 + (FULL ? s : min(s, nsites - 1));
+            double v = Gin[tq + (long)n * col];
+            if (!FULL && (s >= nsites || t >= n)) v = 0.0;
+            az[J][r] = v - ((t == site0 + s) ? 1.0 : 0.0);
+        }
+    // static operands of the triangles and x
+    {
+        const double2 *src = reinterpret_cast<const double2 *>(img_all + (long)unit * LU_STRIDE);
+        double2 *dst = reinterpret_cast<double2 *>(img);
+        for (int i = tid; i < LU_STRIDE / 2; i += 256) dst[i] = src[i];
+    }
+    // R0 tile: thread -> column t' = tid / 4, 16 consecutive s
+    {
+        const int tp = n0 + (tid >> 2), s0 = (tid & 3) * 16;
+        double *d = Rl + (tid >> 2) * FL_LDR + s0;
+        if (FULL) {
+            const double2 *q = reinterpret_cast<const double2 *>(Gin + (long)n * tp + site0 + s0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) reinterpret_cast<double2 *>(d)[i] = q[i];
+        } else {
+            for (int i = 0; i < 16; ++i)
+                d[i] = (tp < n && s0 + i < nsites) ? Gin[(long)n * tp + site0 + s0 + i] : 0.0;
+        }
+    }
+    __syncthreads();
+
+    // Z_J = PT_J (C0'_J + sum_{K<J} Uu_KJ' X_K Z_K);  XZ_J = X_J Z_J
+    d4 xz[4];
+#pragma unroll
+    for (int J = 0; J < 4; ++J) {
+#pragma unroll
+        for (int K = 0; K < J; ++K)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                az[J] = MFMA(img[LU_OFF_U + lu_pair(K, J) * LU_TILE + q * 64 + lane], xz[K][q], az[J]);
+        d4 z = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) z = MFMA(img[LU_OFF_PT + J * LU_TILE + q * 64 + lane], az[J][q], z);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xz[J][r] = z[r] * xs[16 * J + 4 * r + g];
+    }
+    // T'_J = Q_J' (XZ_J + X_J sum_{K>J} L_KJ' T'_K)
+    d4 tt[4];
+#pragma unroll
+    for (int J = 3; J >= 0; --J) {
+        d4 a = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int K = J + 1; K < 4; ++K)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                a = MFMA(img[LU_OFF_L + lu_pair(J, K) * LU_TILE + q * 64 + lane], tt[K][q], a);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a[r] = xz[J][r] + xs[16 * J + 4 * r + g] * a[r];
+        d4 o = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o = MFMA(img[LU_OFF_Q + J * LU_TILE + q * 64 + lane], a[q], o);
+        tt[J] = o;
+    }
+    // G tile += T R0
+#pragma unroll
+    for (int K = 0; K < 4; ++K)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int sk = 16 * K + 4 * q + g;
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+                acc[jt] = MFMA(Rl[(16 * jt + ci) * FL_LDR + sk], tt[K][q], acc[jt]);
+        }
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int tp = n0 + 16 * jt + 4 * r + g;
+            if (FULL || (t < n && tp < n)) Gout[t + (long)n * tp] = acc[jt][r];
+        }
+}
+
+hipError_t launch_sweep_flush_lu(int n, int n_units, const double *Gin, double *Gout, long strideG, int site0,
+                                 int nsites, const double *img, hipStream_t s, hipEvent_t start, hipEvent_t stop)
+{
+    const int tm = (n + 63) / 64, tn = tm;
+    const int groups = (n_units + 7) / 8;
+    const size_t lds = ((size_t)LU_STRIDE + 64 * FL_LDR) * sizeof(double);
+    const bool full = (n % 64 == 0) && nsites == 64;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    static unsigned attr_mask = 0;  // per device (function attributes are per device)
+    if (!(attr_mask & (1u << dev))) {
+        (void)hipFuncSetAttribute((const void *)sweep_flush_lu_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+        (void)hipFuncSetAttribute((const void *)sweep_flush_lu_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+        attr_mask |= 1u << dev;
+    }
+    if (full)
+        hipExtLaunchKernelGGL(sweep_flush_lu_kernel<true>, dim3(groups * 8 * tm * tn), dim3(256), lds, s, start, stop, 0, n,
+                              n_units, Gin, Gout, strideG, site0, nsites, img, tm, tn);
+    else
+        hipExtLaunchKernelGGL(sweep_flush_lu_kernel<false>, dim3(groups * 8 * tm * tn), dim3(256), lds, s, start, stop, 0,
+                              n, n_units, Gin, Gout, strideG, site0, nsites, img, tm, tn);
+    return hipGetLastError();
+}
+
+}  // namespace dqmc
