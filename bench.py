@@ -1,17 +1,22 @@
 #!/usr/bin/env python3
-"""bench.py — DQMC walker-sweeps/s on BASELINE config 3 (attractive Hubbard 16x16, beta=8,
-dtau=0.1: n=256, M=80, K=8; 32 walkers per MI355X), one rank per GPU.
+"""bench.py — DQMC walker-sweeps/s of the hot path, one rank per GPU.
 
-One "step" = one sweep (2*slices `update` calls, src/flavors/DQMC/DQMC.jl:422-437) of every
-walker resident on the rank.  Walkers are independent Markov chains, so N GPUs run N x 32
-walkers (weak scaling) with no data-path collective; the only collective is the RCCL
-all-reduce of the measurement accumulators every `measure_rate` sweeps.
+Workloads (BASELINE.json `configs`), selected with --config:
+  3 (default, the configuration the metric is quoted on): attractive Hubbard 16x16, beta=8, dtau=0.1
+    (n=256, M=80, K=8), 32 walkers per MI355X — weak scaling (N GPUs run N x 32 walkers);
+  4: repulsive Hubbard 16x16, beta=8: 256 walkers in total, split over WORLD_SIZE — strong scaling;
+  5: attractive Hubbard 24x24, beta=20, dtau=0.05 (n=576, M=400, K=40), 64 walkers per GPU — weak scaling.
+
+One "step" = one sweep (2*slices `update` calls, src/flavors/DQMC/DQMC.jl:422-437) of every walker resident on the
+rank.  Walkers are independent Markov chains: there is no data-path collective, only the RCCL all-reduce of the
+measurement accumulators every `measure_rate` sweeps (inside the library: dqmc_reduce).
 
 Prints ONE JSON line (rank 0) with the driver's contract keys plus
-  roofline:     fp64 MFMA roofline of the dominant kernel family (the batched GEMM), from
-                per-launch HIP-event timings on the engine's stream
-  cpu_baseline: the CPU oracle (a restatement of MonteCarlo.jl's algorithm, NOT the Julia
-                package itself) timed on this host's cores on a bounded sample
+  roofline:     whole-sweep algorithmic flops (F = n^3 (12M + 48K - 4) + 4 a M n^3 per block) x rate against
+                the fp64 MFMA peak, with a `kernels` list (device time of every kernel family taken with HIP events
+                attached to the launches of the TIMED region, its share, bound and recomputable fraction)
+  cpu_baseline: the CPU oracle (a restatement of MonteCarlo.jl's algorithm, NOT the Julia package itself) timed on all
+                host cores of this box on a bounded sample, plus the same with its dense products routed to OpenBLAS
 """
 import argparse
 import json
@@ -20,23 +25,39 @@ import sys
 import threading
 import time
 
+os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")  # the "strong CPU" leg runs one single-threaded chain per core
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-L, BETA, DTAU, SAFE_MULT, WALKERS_PER_GPU, BASE_SEED = 16, 8.0, 0.1, 10, 32, 123
-FP64_PEAK_TFLOPS = 78.6  # AMD spec (vector = matrix); not in the in-container guides, see DESIGN.md
+BASE_SEED = 123
+FP64_PEAK_TFLOPS = 78.6  # AMD spec, vector = matrix; reproduced by the in-library probe at full clock (64-cycle MFMA)
+HBM_PEAK_GBS = 8000.0    # /opt/skills/guides/MI355X_MICROARCH.md
+
+CONFIGS = {
+    3: dict(model="attractive", L=16, beta=8.0, dtau=0.1, walkers=32, total=None, scaling="weak", steps=10, warmup=2,
+            name="attractive Hubbard 16x16, beta=8, dtau=0.1 (n=256, M=80, safe_mult=10)"),
+    4: dict(model="repulsive", L=16, beta=8.0, dtau=0.1, walkers=None, total=256, scaling="strong", steps=4, warmup=1,
+            name="repulsive Hubbard 16x16, beta=8, dtau=0.1 (2 blocks of n=256, M=80, safe_mult=10), 256 walkers in total"),
+    5: dict(model="attractive", L=24, beta=20.0, dtau=0.05, walkers=64, total=None, scaling="weak", steps=2, warmup=1,
+            name="attractive Hubbard 24x24, beta=20, dtau=0.05 (n=576, M=400, safe_mult=10)"),
+}
+SAFE_MULT = 10
 
 
-def flops_per_sweep(n, M, K, acc_rate):
-    """algorithmic flops of ONE walker-sweep of the reference algorithm, per block"""
-    gemm = n ** 3 * (12 * M + 24 * K - 4)
-    qr_trsm = n ** 3 * 24 * K
-    rank1 = 4 * acc_rate * M * n ** 3
-    return dict(total=gemm + qr_trsm + rank1, gemm=gemm, qr_trsm=qr_trsm, rank1=rank1)
+def flops_per_sweep(n, nb, M, K, acc_rate):
+    """algorithmic flops of ONE walker-sweep of the reference algorithm, split by the kernel
+    family that serves them here (the four shares add up to F = nb n^3 (12M + 48K - 4 + 4 a M))"""
+    n3 = float(nb) * n ** 3
+    gemm = n3 * (12 * M + 24 * K - 4) + n3 * 8 * K   # reference GEMMs + explicit Q of the 6K UDTs (4/3 n^3 each)
+    qr = n3 * 12 * K                                 # Householder factorisation + column norms, (4/3 + 2/3) n^3 x 6K
+    trsm = n3 * 4 * K                                # rdivp!, n^3 x 4K
+    rank1 = 4 * acc_rate * M * n3                    # accept_local!, 2 n^2 per accepted site
+    return dict(total=gemm + qr + trsm + rank1, gemm=gemm, qr=qr, trsm=trsm, flush=rank1, sweep=0.0, misc=0.0)
 
 
-def cpu_baseline(n_threads, sweeps_each, conf_seed=BASE_SEED):
-    """Oracle chains, one per host core (the reference is one chain per core by construction)."""
+def cpu_baseline(cfg, n_threads, sweeps_each, use_blas, partial_updates=None):
+    """Oracle chains, one per host core (the reference is one chain per core by construction).  Returns
+    (walker-sweeps/s, seconds, description of the sample)."""
     import subprocess
     import tempfile
     from oracle import oracle as O
@@ -49,37 +70,56 @@ def cpu_baseline(n_threads, sweeps_each, conf_seed=BASE_SEED):
     except Exception:
         path = None
     O.lib(path)
+    if use_blas and not O.use_openblas_dgemm(True):
+        return None
     chains = []
     for w in range(n_threads):
-        mc = O.OracleDQMC(L, "attractive", beta=BETA, delta_tau=DTAU, safe_mult=SAFE_MULT)
-        mc.set_conf(O.random_conf(conf_seed + w, mc.N, mc.slices))
-        mc.seed(conf_seed + w)
+        mc = O.OracleDQMC(cfg["L"], cfg["model"], beta=cfg["beta"], delta_tau=cfg["dtau"], safe_mult=SAFE_MULT)
+        mc.set_conf(O.random_conf(BASE_SEED + w, mc.N, mc.slices))
+        mc.seed(BASE_SEED + w)
         chains.append(mc)
 
-    def run(mc, fn, *a):
-        getattr(mc, fn)(*a)
-
     def par(fn, *a):
-        ts = [threading.Thread(target=run, args=(mc, fn) + a) for mc in chains]
+        ts = [threading.Thread(target=lambda m=mc: getattr(m, fn)(*a)) for mc in chains]
         [t.start() for t in ts]
         [t.join() for t in ts]
 
+    def updates(mc, k):
+        for _ in range(k):
+            mc.update()
+
     par("prepare")          # ctypes releases the GIL: the chains really run on separate cores
     t0 = time.time()
-    par("sweeps", sweeps_each)
-    dt = time.time() - t0
-    return n_threads * sweeps_each / dt, dt
+    if partial_updates:     # a bounded part of one sweep (config 5: one sweep is minutes of CPU time)
+        ts = [threading.Thread(target=updates, args=(mc, partial_updates)) for mc in chains]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        dt = time.time() - t0
+        frac = partial_updates / (2.0 * chains[0].slices)
+        rate, what = n_threads * frac / dt, "%d of the %d updates of one sweep" % (partial_updates, 2 * chains[0].slices)
+    else:
+        par("sweeps", sweeps_each)
+        dt = time.time() - t0
+        rate, what = n_threads * sweeps_each / dt, "%d sweeps" % sweeps_each
+    if use_blas:
+        O.use_openblas_dgemm(False)
+    return rate, dt, what
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--walkers", type=int, default=WALKERS_PER_GPU)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS))
+    ap.add_argument("--walkers", type=int, default=None, help="walkers per GPU (overrides the configuration)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sweeps", type=int, default=2)
+    ap.add_argument("--cpu-sweeps", type=int, default=5)
+    ap.add_argument("--no-kernel-timing", action="store_true", help="no HIP events on the launches of the timed region")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    steps = args.steps if args.steps is not None else cfg["steps"]
+    warmup = args.warmup if args.warmup is not None else cfg["warmup"]
 
     # stdout must carry exactly ONE JSON line: native libraries (the RCCL banner, HIP warnings) write
     # to fd 1 as well, so fd 1 is pointed at stderr for the run and the JSON goes to the saved fd
@@ -89,6 +129,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    n_gpus = max(world, 1)
     import torch
     dist = None
     if world > 1 or os.environ.get("BENCH_FORCE_DIST"):  # the env var exercises the RCCL path on one rank
@@ -97,96 +138,135 @@ def main():
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    n_gpus = max(world, 1)
 
     import __graft_entry__ as g
     mc_amd = g.load_package()
-    model = mc_amd.HubbardModelAttractive(L, 2)
-    mc = mc_amd.DQMC(model, beta=BETA, delta_tau=DTAU, safe_mult=SAFE_MULT, n_walkers=args.walkers,
-                     device_id=local_rank, seed=BASE_SEED,
-                     first_walker=mc_amd.walker_range(rank, n_gpus, args.walkers)[0])
-    n, M, K = mc.N, mc.p.slices, mc.p.slices // mc.p.safe_mult
+    if args.walkers is not None:
+        walkers, first = args.walkers, rank * args.walkers
+        total_walkers = walkers * n_gpus
+    elif cfg["total"] is not None:  # fixed total, contiguous blocks of global walker ids
+        total_walkers = cfg["total"]
+        lo, hi = mc_amd.walker_block(rank, n_gpus, total_walkers)
+        walkers, first = hi - lo, lo
+    else:
+        walkers, first = cfg["walkers"], rank * cfg["walkers"]
+        total_walkers = walkers * n_gpus
+    Model = mc_amd.HubbardModelAttractive if cfg["model"] == "attractive" else mc_amd.HubbardModelRepulsive
+    model = Model(cfg["L"], 2)
+    mc = mc_amd.DQMC(model, beta=cfg["beta"], delta_tau=cfg["dtau"], safe_mult=SAFE_MULT, n_walkers=walkers,
+                     device_id=local_rank, seed=BASE_SEED, first_walker=first)
+    n, M = mc.N, mc.p.slices
+    K, nb = M // SAFE_MULT, (2 if cfg["model"] == "repulsive" else 1)
     mc.prepare()
-    acc_dev = torch.zeros(mc.accumulator_size(), dtype=torch.float64, device="cuda:%d" % local_rank)
+    comm = mc_amd.Communicator(dist) if dist is not None else None
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         mc.sweep(1)
+    a0 = mc.analysis_sum()
+    timing = not args.no_kernel_timing
+    if timing:
+        mc.timing_enable(True)   # events ride on the launches of the timed region; drained after the timer stops
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(steps):
         mc.sweep(1)
         if (i + 1) % mc.p.measure_rate == 0:  # measurement sums + RCCL reduction (DQMC.jl:429-436)
             mc.accumulate_greens()
-            mc.export_accumulators(acc_dev.data_ptr())
-            mc_amd.reduce_accumulators(acc_dev, dist)
+            mc.reduce(comm)
     barrier()
     dt = time.perf_counter() - t0
+    tim = mc.timing() if timing else {}
+    if timing:
+        mc.timing_enable(False)
+    a1 = mc.analysis_sum()
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda:%d" % local_rank)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    acc_rate = (a1[1] - a0[1]) / max(1, a1[0] - a0[0])
 
-    # per-kernel-family device time: same steps replayed with HIP events around every launch
-    a0 = mc.analysis(0)
-    mc.timing_enable(True)
-    t_steps = min(args.steps, 3)
-    mc.sweep(t_steps)
-    tim = mc.timing()
-    mc.timing_enable(False)
-    a1 = mc.analysis(0)
-    acc_rate = (a1.acc_local - a0.acc_local) / max(1, a1.prop_local - a0.prop_local)
-
-    value = n_gpus * args.walkers * args.steps / dt
-    F = flops_per_sweep(n, M, K, acc_rate)
-    # algorithmic flops served by the GEMM kernel family per walker-sweep: the reference's GEMMs,
-    # the rank-1 updates (flushed as GEMMs here) and the explicit-Q part of the UDTs (4/3 n^3 each,
-    # 6K per sweep, formed here with compact-WY GEMMs)
-    gemm_alg = F["gemm"] + F["rank1"] + (4.0 / 3.0) * n ** 3 * 6 * K
-    gemm_ms, gemm_launches = tim["gemm"]
-    # HBM-side traffic of one full GEMM launch: PMC passes cannot run inside this process; the
-    # number comes from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE profile (gfx950 x2
-    # FETCH correction applied there), see profiles/*_pmc_gemm.json
+    value = total_walkers * steps / dt
+    ms_per_step = dt / steps * 1e3
+    F = flops_per_sweep(n, nb, M, K, acc_rate)
+    whole_tflops = F["total"] * value / n_gpus / 1e12  # per GPU
+    bounds = {"gemm": "mfma", "flush": "mfma", "qr": "latency", "trsm": "latency", "sweep": "latency", "misc": "hbm"}
+    notes = {
+        "gemm": "gemm_kernel<TA,TB>: slice-matrix products, wraps, the GEMMs of calculate_greens and of compact-WY Q",
+        "flush": "sweep_flush_lu_kernel: the accepted rank-1 updates of 64 sites as block-triangular solves + a K=64 "
+                 "update of G (MFMA); HBM side 16 n^2 B per unit and launch",
+        "qr": "pivoted Householder QR (n sequential column steps per factorisation)",
+        "trsm": "rdivp! and the compact-WY triangle (blocked substitution, MFMA)",
+        "sweep": "sweep_lu4_kernel: Metropolis decisions = conditional elimination of G[c,c] (sequential site chain)",
+        "misc": "udt_finish, copies, propagation-error check",
+    }
+    kernels = []
+    sum_ms = 0.0
+    for fam, (ms, launches) in sorted(tim.items(), key=lambda kv: -kv[1][0]):
+        ms_sweep = ms / steps
+        sum_ms += ms_sweep
+        ent = {"family": fam, "ms_per_sweep": ms_sweep, "share_of_step": ms_sweep / ms_per_step if ms_per_step else 0.0,
+               "launches_per_sweep": launches / steps, "avg_launch_us": ms * 1e3 / max(1, launches),
+               "bound": bounds.get(fam, "latency"), "note": notes.get(fam, "")}
+        fl = F.get(fam, 0.0)
+        if fl > 0 and ms > 0:
+            ent["algorithmic_gflop_per_walker_sweep"] = fl / 1e9
+            ent["achieved_tflops"] = fl * walkers * steps / (ms * 1e-3) / 1e12
+            ent["frac_of_fp64_peak"] = ent["achieved_tflops"] / FP64_PEAK_TFLOPS
+        if fam == "flush" and ms > 0:
+            hb = 16.0 * n * n * walkers * nb * launches  # read + write of G per launch
+            ent["algorithmic_GBps"] = hb / (ms * 1e-3) / 1e9
+            ent["frac_of_hbm_peak"] = ent["algorithmic_GBps"] / HBM_PEAK_GBS
+        kernels.append(ent)
+    # HBM-side traffic of one full GEMM launch: PMC passes cannot run inside this process; the number comes from the
+    # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE profile (gfx950 x2 FETCH correction applied there)
     traffic = None
     try:
         import glob
         pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_gemm.json")))
-        if pm and args.walkers == WALKERS_PER_GPU:
+        if pm and args.config == 3 and walkers == 32:
             traffic = json.load(open(pm[-1]))["traffic_bytes_per_launch"]
     except Exception:
         traffic = None
-    achieved = gemm_alg * args.walkers * t_steps / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    dom = kernels[0] if kernels else None
     out = {
         "metric": "DQMC sweeps/sec, 16x16 Hubbard beta=8 dtau=0.1; achieved % fp64 MFMA roofline",
-        "value": value, "unit": "walker-sweeps/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "value": value, "unit": "walker-sweeps/s", "n_gpus": n_gpus, "steps": steps, "warmup": warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": cfg["scaling"], "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "attractive Hubbard 16x16, beta=8, dtau=0.1 (n=256, M=80, safe_mult=10), "
-                               "%d walkers per MI355X" % args.walkers,
-                   "walkers_per_gpu": args.walkers, "parallelism": "walkers sharded, %d rank(s)" % n_gpus,
-                   "acceptance_rate": acc_rate},
-        "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
-                     "traffic_note": "bytes per full 256^3 x 32 GEMM launch, from profiles/*_pmc_gemm.json",
-                     "kernel": "GEMM family: gemm_kernel<TA,TB> + gemm_flush_kernel (v_mfma_f64_16x16x4_f64)", "launches_per_sweep": gemm_launches / t_steps,
-                     "avg_launch_us": gemm_ms * 1e3 / max(1, gemm_launches)},
-        "whole_sweep": {"algorithmic_gflop_per_walker_sweep": F["total"] / 1e9,
-                        "achieved_tflops": F["total"] * value / n_gpus / 1e12,
-                        "frac_of_fp64_peak": F["total"] * value / n_gpus / 1e12 / FP64_PEAK_TFLOPS},
-        "device_ms_per_sweep": {k: v[0] / t_steps for k, v in tim.items()},
-        "launches_per_sweep": {k: v[1] / t_steps for k, v in tim.items()},
+        "config": {"workload": "%s, %d walkers per MI355X" % (cfg["name"], walkers), "config": args.config,
+                   "walkers_per_gpu": walkers, "total_walkers": total_walkers,
+                   "parallelism": "walkers sharded, %d rank(s)" % n_gpus, "acceptance_rate": acc_rate},
+        "roofline": {"bound": "mfma", "achieved": whole_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": whole_tflops / FP64_PEAK_TFLOPS,
+                     "definition": "SURVEY 8(d): algorithmic flops of the reference algorithm per walker-sweep "
+                                   "(%.3f GFLOP at the measured acceptance) x walker-sweeps/s per GPU" % (F["total"] / 1e9),
+                     "traffic": traffic,
+                     "traffic_note": "HBM bytes of one full 256^3 x 32 gemm_kernel launch, profiles/*_pmc_gemm.json",
+                     "kernels": kernels, "kernel_ms_sum": sum_ms,
+                     "dominant_kernel": None if dom is None else {k: dom.get(k) for k in (
+                         "family", "avg_launch_us", "launches_per_sweep", "bound", "achieved_tflops",
+                         "frac_of_fp64_peak")}},
     }
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
-        cores = min(len(os.sched_getaffinity(0)), 16)
-        v, secs = cpu_baseline(cores, args.cpu_sweeps)
-        out["cpu_baseline"] = {"value": v, "unit": "walker-sweeps/s", "cores": cores, "kind": "port",
-                               "sample": "%d oracle chains (one per core) x %d sweeps of the same 16x16 beta=8 "
-                                         "workload, %.1f s; restatement of MonteCarlo.jl's algorithm, not the "
-                                         "Julia package" % (cores, args.cpu_sweeps, secs)}
+        cores = len(os.sched_getaffinity(0))
+        partial = 20 if args.config == 5 else None
+        r = cpu_baseline(cfg, cores, args.cpu_sweeps, False, partial)
+        out["cpu_baseline"] = {"value": r[0], "unit": "walker-sweeps/s", "cores": cores, "nproc": os.cpu_count(),
+                               "kind": "port",
+                               "sample": "%d oracle chains (one per core, all cores of the box) x %s of the same "
+                                         "workload, %.1f s; restatement of MonteCarlo.jl's algorithm, not the Julia "
+                                         "package" % (cores, r[2], r[1])}
+        rb = cpu_baseline(cfg, cores, args.cpu_sweeps, True, partial)
+        if rb is not None:
+            out["cpu_baseline"]["strong_cpu"] = {
+                "value": rb[0], "unit": "walker-sweeps/s", "cores": cores,
+                "sample": "same chains with the dense products routed to OpenBLAS dgemm (scipy's BLAS, 1 thread per "
+                          "chain), %s, %.1f s; QR / rank-1 updates stay literal" % (rb[2], rb[1])}
     if rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())

@@ -228,6 +228,28 @@ int dqmc_susceptibilities_size(dqmc_handle *h, size_t *n_doubles);
 int dqmc_get_susceptibilities(dqmc_handle *h, double *host_out);
 int dqmc_export_susceptibilities(dqmc_handle *h, void *device_out);
 
+/* ---- measurement reduction over ranks -------------------
+ * One process (or thread) per GPU; walkers never interact, the only collective is the reduction of the measurement
+ * sums every `measure_rate` sweeps (DQMC.jl:429-436).  dqmc_reduce packs EVERY accumulator of the handle (Green's
+ * function sums, correlations, pairing, susceptibilities - whichever are configured) and the DQMCAnalysis counters
+ * of its walkers (prop_local, acc_local, MagnitudeStats sum / count / max / min, DQMC.jl:4-47) into one device
+ * buffer [sums | 2 maxima | 2 minima] and runs ncclAllReduce (sum, max, min) over RCCL on the handle's stream; the
+ * accumulators then hold the global sums on every rank and dqmc_get_reduced_stats the global counters.
+ * comm == NULL reduces over the walkers of this handle only.  A host that brings its own collective (MPI from
+ * Julia, gloo in this repository's tests) uses dqmc_reduce_export -> reduce (sums, then maxima, then minima; layout
+ * above) -> dqmc_reduce_import instead. */
+typedef struct dqmc_comm dqmc_comm;
+/* ncclGetUniqueId on rank 0 (128 bytes), to be broadcast by the host's own means */
+int dqmc_comm_unique_id(void *id128);
+/* ncclCommInitRank on device_id (collective: every rank calls it with the same id) */
+int dqmc_comm_init(const void *id128, int32_t nranks, int32_t rank, int32_t device_id, dqmc_comm **out);
+int dqmc_comm_destroy(dqmc_comm *c);
+int dqmc_reduce(dqmc_handle *h, dqmc_comm *comm);
+int dqmc_reduce_size(dqmc_handle *h, size_t *n_doubles /* sums + 4 */);
+int dqmc_reduce_export(dqmc_handle *h, double *host_out);
+int dqmc_reduce_import(dqmc_handle *h, const double *host_in);
+int dqmc_get_reduced_stats(dqmc_handle *h, dqmc_stats *out);
+
 /* ---- batched linalg primitives (unit parity with test/slice_matrices.jl) --
  * host in / host out, `batch` independent n x n problems, run on device_id.  */
 /* vmul! family (src/linalg/general.jl:7-56): C = op(A)*op(B); transa/transb 0|1 */

@@ -12,7 +12,8 @@ from .lattices import (Chain, EachLocalQuadByDistance, EachSitePairByDistance, S
                        build_checkerboard)
 from .models import (HubbardModel, HubbardModelAttractive, HubbardModelRepulsive,  # noqa: F401
                      rand_conf)
-from .sharding import reduce_accumulators, walker_range, walker_seeds  # noqa: F401
+from .sharding import (Communicator, reduce_accumulators, walker_block, walker_range,  # noqa: F401
+                       walker_seeds)
 from .dqmc import (DQMC, DQMCParameters, calculate_greens_AVX, device_count,  # noqa: F401
                    checkerboard_exponentials, hopping_exponentials, mfma_f64_peak, rdivp, udt_AVX_pivot, vmul)
 

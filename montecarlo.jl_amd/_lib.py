@@ -101,6 +101,14 @@ SIGNATURES = {
     "dqmc_susceptibilities_size": (C.c_int, [_H, C.POINTER(C.c_size_t)]),
     "dqmc_get_susceptibilities": (C.c_int, [_H, _dp]),
     "dqmc_export_susceptibilities": (C.c_int, [_H, C.c_void_p]),
+    "dqmc_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "dqmc_comm_init": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_H)]),
+    "dqmc_comm_destroy": (C.c_int, [_H]),
+    "dqmc_reduce": (C.c_int, [_H, _H]),
+    "dqmc_reduce_size": (C.c_int, [_H, C.POINTER(C.c_size_t)]),
+    "dqmc_reduce_export": (C.c_int, [_H, _dp]),
+    "dqmc_reduce_import": (C.c_int, [_H, _dp]),
+    "dqmc_get_reduced_stats": (C.c_int, [_H, C.POINTER(Stats)]),
     "dqmc_vmul": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _dp, _dp, _dp]),
     "dqmc_udt_pivot": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _dp, _dp, _dp, _i64p, C.c_int32]),
     "dqmc_rdivp": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _dp, _dp, _i64p]),

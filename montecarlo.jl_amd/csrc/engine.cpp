@@ -16,8 +16,14 @@
 
 #include "../../include/dqmc_hip.h"
 #include "kernels.h"
+#include <rccl/rccl.h>
 
 using namespace dqmc;
+
+struct dqmc_comm {
+    ncclComm_t comm = nullptr;
+    int nranks = 1, rank = 0, device = 0;
+};
 
 static thread_local std::string g_create_error;
 
@@ -72,6 +78,11 @@ struct dqmc_handle {
     long long fam_n[DQMC_K_COUNT] = {0};
     std::vector<void *> allocs;
     QrCoopWorkspace qr_ws;
+    // measurement reduction (dqmc_reduce): packed device buffer [sums | maxima | minima]
+    double *red_buf = nullptr;
+    size_t red_cap = 0;
+    dqmc_stats red_stats{};
+    bool red_valid = false;
 };
 
 // ---------------------------------------------------------------------------
@@ -256,12 +267,13 @@ static int set_ones(dqmc_handle *h, double *d)
 
 static int alloc_qr_workspace(dqmc_handle *h)
 {
+    // device-side error word (bit 0: cooperative QR hand-off timed out, bit 1: sweep elimination hand-off timed out)
+    CHK(dalloc(h, &h->qr_ws.errflag, (size_t)1));
     if (h->n > 256) return 0;
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, h->p.device_id));
     const size_t slots = (size_t)((h->units + 7) / 8) * 8 * 2 * 8;  // units x parity x 8 parts
     CHK(dalloc(h, &h->qr_ws.mailbox, slots * QR_COOP_SLOT));
-    CHK(dalloc(h, &h->qr_ws.errflag, (size_t)1));
     // co-residency: the kernel's 200 VGPRs admit 2 workgroups of 256 threads per CU
     h->qr_ws.max_blocks = prop.multiProcessorCount * 2;
     h->qr_ws.epoch = 0;
@@ -272,7 +284,11 @@ static int check_qr_workspace(dqmc_handle *h)
     if (!h->qr_ws.errflag) return 0;
     int e = 0;
     HIPCHK(hipMemcpy(&e, h->qr_ws.errflag, sizeof(int), hipMemcpyDeviceToHost));
-    if (e) return fail(h, DQMC_ERR_HIP, "cooperative QR: hand-off timed out");
+    if (e) {  // reported once: the flag is cleared, the data of the failed call is not trustworthy
+        HIPCHK(hipMemset(h->qr_ws.errflag, 0, sizeof(int)));
+        return fail(h, DQMC_ERR_HIP, (e & 1) ? "cooperative QR: hand-off timed out (results of this call are invalid)"
+                                             : "sweep elimination: hand-off timed out (results of this call are invalid)");
+    }
     return 0;
 }
 
@@ -519,7 +535,7 @@ static int sweep_spatial(dqmc_handle *h)
             hipEvent_t a, b;
             timing_events(h, &a, &b);
             HIPCHK(launch_sweep_lu(h->n, h->nb, h->W, cur, h->nn, cslice, (long)h->N * h->M, site0, ns, h->lu_img, h->sc,
-                                   h->rng, h->stats, h->p.check_sign_problem, h->stream, a, b));
+                                   h->rng, h->stats, h->p.check_sign_problem, h->qr_ws.errflag, h->stream, a, b));
             CHK(timing_push(h, a, b, DQMC_K_SWEEP));
             timing_events(h, &a, &b);
             HIPCHK(launch_sweep_flush_lu(h->n, h->units, cur, alt, h->nn, site0, ns, h->lu_img, h->stream, a, b));
@@ -942,6 +958,7 @@ int dqmc_calculate_greens_at(dqmc_handle *h, int32_t w, int32_t slice, double *o
     if (slice < 0 || slice > h->M) return fail(h, DQMC_ERR_INVALID, "slice out of range 0..slices");
     CHK(calculate_greens_from_scratch(h, slice, h->greens_temp));
     HIPCHK(hipStreamSynchronize(h->stream));
+    CHK(check_qr_workspace(h));
     HIPCHK(hipMemcpy(out, h->greens_temp + (size_t)w * h->nb * h->nn, sizeof(double) * h->nb * h->nn,
                      hipMemcpyDeviceToHost));
     return DQMC_OK;
@@ -1179,6 +1196,162 @@ int dqmc_export_accumulators(dqmc_handle *h, void *device_out)
 
 #include "unequal_time.inl"
 
+// ---------------------------------------------------------------------------
+// Measurement reduction over ranks: every accumulator the handle keeps and the DQMCAnalysis
+// counters, as ONE packed device buffer of doubles [sums | maxima | minima]:
+//   sums   = acc (G, G.^2, occupation, count), correlations, pairing, susceptibilities (each if configured),
+//            then prop_local, acc_local, negative_probability {sum, count}, propagation_error {sum, count}
+//   maxima = negative_probability.max, propagation_error.max      minima = the two .min
+// (MagnitudeStats, DQMC.jl:4-47).  dqmc_reduce runs three ncclAllReduce (sum / max / min) on the handle's stream;
+// a host-side collective (MPI from Julia, gloo in the tests) can do the same through export / import.
+static const size_t RED_STAT_SUMS = 6;
+static size_t red_nsum(dqmc_handle *h)
+{
+    return h->acc_n + h->corr_n + h->pc_n + (h->ut ? h->ut->sus_n : 0) + RED_STAT_SUMS;
+}
+static int red_pack(dqmc_handle *h)
+{
+    const size_t nsum = red_nsum(h), tot = nsum + 4;
+    if (h->red_cap < tot) {
+        CHK(dalloc(h, &h->red_buf, tot));
+        h->red_cap = tot;
+    }
+    size_t off = 0;
+    auto put = [&](const double *src, size_t cnt) -> int {
+        if (cnt) HIPCHK(hipMemcpyAsync(h->red_buf + off, src, cnt * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        off += cnt;
+        return 0;
+    };
+    CHK(put(h->acc, h->acc_n));
+    CHK(put(h->corr_acc, h->corr_n));
+    CHK(put(h->pc_acc, h->pc_n));
+    if (h->ut) CHK(put(h->ut->sus_acc, h->ut->sus_n));
+    // counters of the local walkers, reduced on the host in walker order
+    std::vector<DevStats> st(h->W);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(st.data(), h->stats, sizeof(DevStats) * h->W, hipMemcpyDeviceToHost));
+    double tail[RED_STAT_SUMS + 4] = {0, 0, 0, 0, 0, 0, -INFINITY, -INFINITY, INFINITY, INFINITY};
+    for (const auto &x : st) {
+        tail[0] += (double)x.prop_local;
+        tail[1] += (double)x.acc_local;
+        tail[2] += x.negative_probability.sum;
+        tail[3] += (double)x.negative_probability.count;
+        tail[4] += x.propagation_error.sum;
+        tail[5] += (double)x.propagation_error.count;
+        tail[6] = std::fmax(tail[6], x.negative_probability.max);
+        tail[7] = std::fmax(tail[7], x.propagation_error.max);
+        tail[8] = std::fmin(tail[8], x.negative_probability.min);
+        tail[9] = std::fmin(tail[9], x.propagation_error.min);
+    }
+    HIPCHK(hipMemcpy(h->red_buf + off, tail, sizeof(tail), hipMemcpyHostToDevice));
+    return 0;
+}
+static int red_unpack(dqmc_handle *h)
+{
+    size_t off = 0;
+    auto get = [&](double *dst, size_t cnt) -> int {
+        if (cnt) HIPCHK(hipMemcpyAsync(dst, h->red_buf + off, cnt * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        off += cnt;
+        return 0;
+    };
+    CHK(get(h->acc, h->acc_n));
+    CHK(get(h->corr_acc, h->corr_n));
+    CHK(get(h->pc_acc, h->pc_n));
+    if (h->ut) CHK(get(h->ut->sus_acc, h->ut->sus_n));
+    double tail[RED_STAT_SUMS + 4];
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(tail, h->red_buf + off, sizeof(tail), hipMemcpyDeviceToHost));
+    dqmc_stats &r = h->red_stats;
+    r.prop_local = (int64_t)std::llround(tail[0]);
+    r.acc_local = (int64_t)std::llround(tail[1]);
+    r.imaginary_probability = {-INFINITY, INFINITY, 0.0, 0};
+    r.negative_probability = {tail[6], tail[8], tail[2], (int64_t)std::llround(tail[3])};
+    r.propagation_error = {tail[7], tail[9], tail[4], (int64_t)std::llround(tail[5])};
+    h->red_valid = true;
+    return 0;
+}
+int dqmc_comm_unique_id(void *id128)
+{
+    if (!id128) return DQMC_ERR_INVALID;
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    ncclUniqueId id;
+    if (ncclGetUniqueId(&id) != ncclSuccess) return fail(nullptr, DQMC_ERR_HIP, "ncclGetUniqueId failed");
+    std::memcpy(id128, &id, sizeof(id));
+    return DQMC_OK;
+}
+int dqmc_comm_init(const void *id128, int32_t nranks, int32_t rank, int32_t device_id, dqmc_comm **out)
+{
+    if (!id128 || !out || nranks < 1 || rank < 0 || rank >= nranks) return fail(nullptr, DQMC_ERR_INVALID, "dqmc_comm_init: bad arguments");
+    *out = nullptr;
+    if (hipSetDevice(device_id) != hipSuccess) return fail(nullptr, DQMC_ERR_NO_DEVICE, "dqmc_comm_init: hipSetDevice failed");
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof(id));
+    dqmc_comm *c = new dqmc_comm();
+    c->nranks = nranks; c->rank = rank; c->device = device_id;
+    const ncclResult_t r = ncclCommInitRank(&c->comm, nranks, id, rank);
+    if (r != ncclSuccess) {
+        delete c;
+        return fail(nullptr, DQMC_ERR_HIP, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
+    }
+    *out = c;
+    return DQMC_OK;
+}
+int dqmc_comm_destroy(dqmc_comm *c)
+{
+    if (!c) return DQMC_OK;
+    if (c->comm) (void)ncclCommDestroy(c->comm);
+    delete c;
+    return DQMC_OK;
+}
+int dqmc_reduce_size(dqmc_handle *h, size_t *n_doubles)
+{
+    if (!h || !n_doubles) return DQMC_ERR_INVALID;
+    *n_doubles = red_nsum(h) + 4;
+    return DQMC_OK;
+}
+int dqmc_reduce(dqmc_handle *h, dqmc_comm *comm)
+{
+    ENTER(h);
+    CHK(red_pack(h));
+    if (comm && comm->comm) {
+        if (comm->device != h->p.device_id) return fail(h, DQMC_ERR_INVALID, "dqmc_reduce: communicator bound to another device");
+        const size_t nsum = red_nsum(h);
+        ncclResult_t r = ncclGroupStart();
+        if (r == ncclSuccess) r = ncclAllReduce(h->red_buf, h->red_buf, nsum, ncclDouble, ncclSum, comm->comm, h->stream);
+        if (r == ncclSuccess) r = ncclAllReduce(h->red_buf + nsum, h->red_buf + nsum, 2, ncclDouble, ncclMax, comm->comm, h->stream);
+        if (r == ncclSuccess) r = ncclAllReduce(h->red_buf + nsum + 2, h->red_buf + nsum + 2, 2, ncclDouble, ncclMin, comm->comm, h->stream);
+        const ncclResult_t r2 = ncclGroupEnd();
+        if (r != ncclSuccess || r2 != ncclSuccess)
+            return fail(h, DQMC_ERR_HIP, std::string("ncclAllReduce: ") + ncclGetErrorString(r != ncclSuccess ? r : r2));
+    }
+    CHK(red_unpack(h));
+    return DQMC_OK;
+}
+// host-mediated variant: pack -> host buffer (reduce it with any collective: sums first, then 2 maxima, 2 minima)
+int dqmc_reduce_export(dqmc_handle *h, double *host_out)
+{
+    ENTER(h);
+    CHK(red_pack(h));
+    HIPCHK(hipMemcpy(host_out, h->red_buf, (red_nsum(h) + 4) * sizeof(double), hipMemcpyDeviceToHost));
+    return DQMC_OK;
+}
+int dqmc_reduce_import(dqmc_handle *h, const double *host_in)
+{
+    ENTER(h);
+    if (h->red_cap < red_nsum(h) + 4) return fail(h, DQMC_ERR_STATE, "call dqmc_reduce_export first");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(h->red_buf, host_in, (red_nsum(h) + 4) * sizeof(double), hipMemcpyHostToDevice));
+    CHK(red_unpack(h));
+    return DQMC_OK;
+}
+int dqmc_get_reduced_stats(dqmc_handle *h, dqmc_stats *out)
+{
+    if (!h || !out) return DQMC_ERR_INVALID;
+    if (!h->red_valid) return fail(h, DQMC_ERR_STATE, "call dqmc_reduce first");
+    *out = h->red_stats;
+    return DQMC_OK;
+}
+
 int dqmc_timing_enable(dqmc_handle *h, int32_t on)
 {
     ENTER(h);
@@ -1289,6 +1462,7 @@ int dqmc_udt_pivot(int32_t device_id, int32_t n, int32_t batch, double *U, doubl
     SHIP(hipMemcpy(dT, T, un * sizeof(double), hipMemcpyHostToDevice));
     SCHK(udt(h, dT, dU, dD, dTo, apply != 0));
     SHIP(hipStreamSynchronize(h->stream));
+    SCHK(check_qr_workspace(h));
     SHIP(hipMemcpy(U, dU, un * sizeof(double), hipMemcpyDeviceToHost));
     SHIP(hipMemcpy(D, dD, uv * sizeof(double), hipMemcpyDeviceToHost));
     SHIP(hipMemcpy(T, apply ? dTo : dT, un * sizeof(double), hipMemcpyDeviceToHost));
@@ -1341,6 +1515,7 @@ int dqmc_calculate_greens(int32_t device_id, int32_t n, int32_t batch, const dou
     SHIP(hipMemcpy(h->Dr, Dr, uv * sizeof(double), hipMemcpyHostToDevice));
     SCHK(calculate_greens(h, dG));
     SHIP(hipStreamSynchronize(h->stream));
+    SCHK(check_qr_workspace(h));
     SHIP(hipMemcpy(G, dG, un * sizeof(double), hipMemcpyDeviceToHost));
     scratch_free(h);
     return DQMC_OK;

@@ -169,8 +169,8 @@ hipError_t launch_sweep_chunk(int n, int nb, int n_walkers, int model, double *G
 size_t sweep_lu_image_doubles();
 hipError_t launch_sweep_lu(int n, int nb, int n_walkers, const double *G, long strideG, int8_t *conf_slice,
                            long conf_stride, int site0, int nsites, double *img, SweepConsts sc, WalkerRng *rng,
-                           DevStats *stats, int check_sign, hipStream_t s, hipEvent_t start = nullptr,
-                           hipEvent_t stop = nullptr);
+                           DevStats *stats, int check_sign, int *errflag, hipStream_t s,
+                           hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
 hipError_t launch_sweep_flush_lu(int n, int n_units, const double *Gin, double *Gout, long strideG, int site0,
                                  int nsites, const double *img, hipStream_t s, hipEvent_t start = nullptr,
                                  hipEvent_t stop = nullptr);

@@ -828,7 +828,7 @@ __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double
         // (pos/colat are rewritten by thread 0 only after the barriers of the next step)
     }
     if (s_abort) {
-        if (tid == 0) atomicExch(errflag, 1);
+        if (tid == 0) atomicOr(errflag, 1);
         return;
     }
     __syncthreads();

@@ -24,6 +24,7 @@
 // tools/proto/lu_sweep_proto.py and in the oracle).
 #include "kernels.h"
 #include <hip/hip_ext.h>
+#include <cstdlib>
 
 namespace dqmc {
 
@@ -245,19 +246,404 @@ __global__ __launch_bounds__(64) void sweep_lu_kernel(int n, const double *__res
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The same elimination on the four SIMDs of a CU: wave J owns block column J of S and of S' (tiles (I, J), I <= J).
+// In block I0 wave I0 is the PIVOT: it runs the decisions on its diagonal tiles and publishes, per accepted site,
+// the two A operands (x G[:, s], x G[s, :] on the block's rows) through LDS; waves J > I0 apply them to their strip
+// tiles (I0, J), exchange the finished strip rows once per panel and do the k = 4 updates of their later tiles;
+// wave (I0 + 1) % 4 also carries the two triangular inverses of the diagonal block.  Each slot of the step ring is
+// written once per launch (no reuse), flags are LDS words with workgroup-scope release / acquire; every wait is
+// bounded (a time-out sets *errflag and lets all waves run through).
+constexpr int LU4_SPIN = 1 << 21;
+template <int NB>
+struct Lu4Smem {
+    double2 aST[NB][64][64];     // [block][site][lane]: the two A operands of an accepted site, x * (column s on the
+                                 // block rows) for the S update and x * (row s on the block columns) for the S' update
+    double xs[NB][64];           // x of every site (0 = rejected), zeroed at kernel start
+    double strip[12][NB][2][64]; // finished strip registers of (I0, panel, wave): S row panel, S' row panel
+    double negv[64];
+    int step[64];                // 0: not decided; else (ndraw << 3) | (exhausted << 2) | (2: accepted, 1: rejected)
+    int sflag[12];
+    unsigned acc16[4], neg16[4];
+    int ndraw[4], exh[4];
+    int abort;
+};
+__host__ __device__ constexpr int lu4_strip_idx(int I0, int r0, int I) { return I0 == 0 ? r0 * 2 + (I - 1) : 8 + r0; }
+
+// LDS executes the DS instructions of one wave in issue order, so a flag written (read) after its payload in program
+// order needs no s_waitcnt in between; the empty asm statements only pin the program order for the compiler.
+#define LU4_ORDER() asm volatile("" ::: "memory")
+
+// wave-uniform wait on an LDS word: the loaded value is made scalar right away, so that the loop and everything that
+// depends on the flag stays on the scalar unit
+__device__ __forceinline__ int lu4_wait(int *flag, int *abortf)
+{
+    int v = 0;
+    for (int it = 0; it < LU4_SPIN; ++it) {
+        v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if (v) break;
+        if ((it & 63) == 63 &&
+            __builtin_amdgcn_readfirstlane(__hip_atomic_load(abortf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)))
+            return -1;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    if (!v) {
+        __hip_atomic_store(abortf, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return -1;
+    }
+    LU4_ORDER();
+    return v;
+}
+// 1 / r to working precision: v_rcp_f64 and two Newton steps (the correctly rounded quotient is not needed: x only
+// enters the update of G, never a decision)
+__device__ __forceinline__ double lu4_rcp(double r)
+{
+    double y = __builtin_amdgcn_rcp(r);
+    double e = __builtin_fma(-r, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-r, y, 1.0);
+    return __builtin_fma(y, e, y);
+}
+
+extern __shared__ __attribute__((aligned(16))) double lu4_lds[];
+// one function per wave role (not inlined into each other: each gets its own register allocation)
+template <int NB, bool FULL, int J>
+__device__ __noinline__ void lu4_wave(int n, const double *__restrict__ Gall, long strideG, int w, int site0,
+                                      int nsites, double *__restrict__ img_all, const SweepConsts &sc,
+                                      unsigned long long cbits_v, double uvec, int check_sign)
+{
+    Lu4Smem<NB> &sm = *reinterpret_cast<Lu4Smem<NB> *>(lu4_lds);
+    const int lane = threadIdx.x & 63, g = lane >> 4, ci = lane & 15;
+    const unsigned long long cbits =
+        ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(cbits_v >> 32)) << 32) |
+        (unsigned)__builtin_amdgcn_readfirstlane((int)(cbits_v & 0xffffffffull));
+    d4 S[NB][J + 1], ST[NB][J + 1];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const double *__restrict__ G = Gall + (long)(w * NB + b) * strideG + (long)site0 * n + site0;
+#pragma unroll
+        for (int I = 0; I <= J; ++I)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rho = 16 * I + 4 * r + g, kap = 16 * J + ci;  // S[rho][kap]; ST: S[kap][rho]
+                if (FULL) {
+                    S[b][I][r] = G[rho + (long)n * kap];
+                    ST[b][I][r] = G[kap + (long)n * rho];
+                } else {
+                    const bool ok = rho < nsites && kap < nsites;
+                    const int rc = min(rho, nsites - 1), kc = min(kap, nsites - 1);
+                    const double a = G[rc + (long)n * kc], c = G[kc + (long)n * rc];
+                    S[b][I][r] = ok ? a : 0.0;
+                    ST[b][I][r] = ok ? c : 0.0;
+                }
+            }
+    }
+    const double g0 = sc.gamma[0], g1 = sc.gamma[1], e0 = sc.ebos[0], e1 = sc.ebos[1];
+    const double du0 = sc.dup[0], du1 = sc.dup[1], dd0 = sc.ddn[0], dd1 = sc.ddn[1];
+    int lastflag = 0;  // the newest step word seen (carries the draw counter from pivot to pivot)
+
+#pragma unroll
+    for (int I0 = 0; I0 < 4; ++I0) {
+        if (!FULL && 16 * I0 >= nsites) break;
+        const bool PIV = (I0 == J), HLP = (J > I0), PTQ = (J == ((I0 + 1) & 3));
+        if (!PIV && !HLP && !PTQ) continue;
+        d4 PT[NB], Q[NB];
+        if (PTQ) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) PT[b][r] = Q[b][r] = (4 * r + g == ci) ? 1.0 : 0.0;
+        }
+        int ndraw = (lastflag >> 3) & 0xfff, exhausted = (lastflag >> 2) & 1;
+        unsigned accb = 0, negb = 0;
+        double negv = 0.0;
+        // The diagonal entry the next decision needs is carried as a scalar: S[s+1][s+1] + x S[s+1][s] S[s][s+1]
+        // from registers that the MFMAs of site s have not touched yet, so a decision never waits for an MFMA.
+        double dcur[NB];
+        if (PIV) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) dcur[b] = readlane_d(S[b][J][0], 0);
+        }
+#pragma unroll
+        for (int r0 = 0; r0 < 4; ++r0) {
+            double xv4[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) xv4[b] = 0.0;
+            unsigned panel_acc = 0;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int c = 4 * r0 + ks, s = 16 * I0 + c;
+                if (!FULL && s >= nsites) continue;
+                if (PIV) {
+                    const int spin = (int)((cbits >> s) & 1ull);
+                    double det, p, xb[NB];
+                    if (NB == 1) {  // HubbardModelAttractive.jl:113-127
+                        const double gamma = spin ? g1 : g0;
+                        const double r = 1.0 + gamma * (1.0 - dcur[0]);
+                        det = r * r;
+                        p = (spin ? e1 : e0) * det;
+                        xb[0] = gamma * lu4_rcp(r);  // Attractive.jl:149: x = gamma / (1 + gamma * IG[i])
+                    } else {        // HubbardModelRepulsive.jl:128-156,174-191
+                        const double D0 = spin ? du1 : du0, D1 = spin ? dd1 : dd0;
+                        const double R0 = 1.0 + D0 * (1.0 - dcur[0]), R1 = 1.0 + D1 * (1.0 - dcur[NB - 1]);
+                        det = R0 * R1;
+                        p = det;
+                        const double inv_div = lu4_rcp(det);
+                        xb[0] = (R1 * inv_div) * D0;
+                        xb[NB - 1] = (R0 * inv_div) * D1;
+                        if (check_sign && det < 0.0) {
+                            negb |= 1u << c;
+                            negv = lane == s ? det : negv;
+                        }
+                    }
+                    bool acc;
+                    if (p > 1.0) acc = true;  // DQMC.jl:573: rand() is consumed only when p <= 1
+                    else {
+                        const double u = readlane_d(uvec, ndraw);
+                        ++ndraw;
+                        if (u == 2.0) exhausted = 1;
+                        acc = u < p;
+                    }
+                    const int word = (ndraw << 3) | (exhausted << 2);
+                    const bool more = c < 15 && (FULL || s + 1 < nsites);
+                    constexpr int dummy = 0;
+                    (void)dummy;
+                    const int c1 = c + 1, l1 = 16 * (c1 & 3) + c1;  // lane of S[s+1][s+1] in register c1 >> 2
+                    if (__builtin_amdgcn_readfirstlane((int)acc)) {
+                        accb |= 1u << c;
+                        const bool lm2 = g == ks && ci > c;
+#pragma unroll
+                        for (int b = 0; b < NB; ++b) {
+                            const double x = xb[b];
+                            const double mS = lm2 ? S[b][J][r0] : 0.0, mT = lm2 ? ST[b][J][r0] : 0.0;
+                            const double aS = x * mT, aT = x * mS;
+                            if (more) {
+                                const double t = readlane_d(aS * mS, 16 * ks + c1);  // x S[s+1][s] S[s][s+1]
+                                dcur[b] = readlane_d(S[b][J][c1 >> 2], l1) + t;
+                            }
+                            S[b][J] = MFMA(aS, mS, S[b][J]);
+                            sm.aST[b][s][lane] = make_double2(aS, aT);
+                            sm.xs[b][s] = x;
+                            ST[b][J] = MFMA(aT, mT, ST[b][J]);
+                        }
+                        LU4_ORDER();
+                        __hip_atomic_store(&sm.step[s], word | 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    } else {
+                        __hip_atomic_store(&sm.step[s], word | 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (more) {
+#pragma unroll
+                            for (int b = 0; b < NB; ++b) dcur[b] = readlane_d(S[b][J][c1 >> 2], l1);
+                        }
+                    }
+                    lastflag = word;
+                } else {
+                    // flag and payload are requested together (in this order); the payload is only valid if the
+                    // flag was already set
+                    int v = 0;
+                    double2 pay[NB];
+                    double xh[NB];
+                    for (int it = 0; it < LU4_SPIN; ++it) {
+                        const int vr = __hip_atomic_load(&sm.step[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        LU4_ORDER();
+#pragma unroll
+                        for (int b = 0; b < NB; ++b) {
+                            pay[b] = sm.aST[b][s][lane];
+                            xh[b] = sm.xs[b][s];
+                        }
+                        v = __builtin_amdgcn_readfirstlane(vr);
+                        if (v) break;
+                        if ((it & 63) == 63 && __builtin_amdgcn_readfirstlane(__hip_atomic_load(
+                                                   &sm.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) {
+                            v = -1;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    if (v == 0) {
+                        __hip_atomic_store(&sm.abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        v = -1;
+                    }
+                    if (v > 0) lastflag = v;
+                    if (v > 0 && (v & 3) == 2) {
+                        panel_acc |= 1u << ks;
+#pragma unroll
+                        for (int b = 0; b < NB; ++b) {
+                            const double aS = pay[b].x, aT = pay[b].y;
+                            if (HLP) {
+                                xv4[b] = g == ks ? xh[b] : xv4[b];
+                                S[b][I0] = MFMA(aS, S[b][I0][r0], S[b][I0]);
+                                ST[b][I0] = MFMA(aT, ST[b][I0][r0], ST[b][I0]);
+                            }
+                            if (PTQ) {
+                                PT[b] = MFMA(aT, PT[b][r0], PT[b]);  // PT[j][:] += x G[s, j] PT[s][:]
+                                Q[b] = MFMA(aS, Q[b][r0], Q[b]);     // Q[k][:]  += x G[k, s] Q[s][:]
+                            }
+                        }
+                    }
+                }
+            }
+            // panel end: the four sites applied to the later tiles of my block column with k = 4 MFMAs
+            if (HLP && panel_acc != 0) {
+                if (J < 3) {  // my finished strip rows for the waves to my right
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) {
+                        sm.strip[lu4_strip_idx(I0, r0, J)][b][0][lane] = S[b][I0][r0];
+                        sm.strip[lu4_strip_idx(I0, r0, J)][b][1][lane] = ST[b][I0][r0];
+                    }
+                    LU4_ORDER();
+                    __hip_atomic_store(&sm.sflag[lu4_strip_idx(I0, r0, J)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {  // tile (J, J) first: it is the next pivot's diagonal tile
+                    S[b][J] = MFMA(xv4[b] * ST[b][I0][r0], S[b][I0][r0], S[b][J]);
+                    ST[b][J] = MFMA(xv4[b] * S[b][I0][r0], ST[b][I0][r0], ST[b][J]);
+                }
+#pragma unroll
+                for (int I = I0 + 1; I < J; ++I) {
+                    const int ok = lu4_wait(&sm.sflag[lu4_strip_idx(I0, r0, I)], &sm.abort);
+                    if (ok > 0) {
+#pragma unroll
+                        for (int b = 0; b < NB; ++b) {
+                            const double rs = sm.strip[lu4_strip_idx(I0, r0, I)][b][0][lane];
+                            const double rt = sm.strip[lu4_strip_idx(I0, r0, I)][b][1][lane];
+                            S[b][I] = MFMA(xv4[b] * rt, S[b][I0][r0], S[b][I]);
+                            ST[b][I] = MFMA(xv4[b] * rs, ST[b][I0][r0], ST[b][I]);
+                        }
+                    }
+                }
+            }
+        }
+        // block row I0 is final: register images for the flush kernel
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            double *__restrict__ img = img_all + (long)(w * NB + b) * LU_STRIDE;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int tpos = (ci >> 2) * 64 + 16 * (ci & 3) + 4 * r + g;
+                if (HLP) {
+                    img[LU_OFF_U + lu_pair(I0, J) * LU_TILE + r * 64 + lane] = S[b][I0][r];
+                    img[LU_OFF_L + lu_pair(I0, J) * LU_TILE + tpos] = ST[b][I0][r];
+                }
+                if (PTQ) {
+                    img[LU_OFF_PT + I0 * LU_TILE + tpos] = PT[b][r];
+                    img[LU_OFF_Q + I0 * LU_TILE + r * 64 + lane] = Q[b][r];
+                }
+            }
+            if (PIV && (lane >> 4) == I0) img[LU_IMG + lane] = sm.xs[b][lane];
+        }
+        if (PIV) {
+            if (lane == 0) {
+                sm.acc16[I0] = accb;
+                sm.neg16[I0] = negb;
+                sm.ndraw[I0] = ndraw;
+                sm.exh[I0] = exhausted;
+            }
+            if (NB == 2 && (lane >> 4) == I0) sm.negv[lane] = negv;
+        }
+    }
+}
+
+template <int NB, bool FULL>
+__global__ __launch_bounds__(256) void sweep_lu4_kernel(int n, const double *__restrict__ Gall, long strideG,
+                                                       int8_t *__restrict__ conf_slice, long conf_stride, int site0,
+                                                       int nsites, double *__restrict__ img_all, SweepConsts sc,
+                                                       WalkerRng *rngs, DevStats *stats, int check_sign, int *errflag)
+{
+    Lu4Smem<NB> &sm = *reinterpret_cast<Lu4Smem<NB> *>(lu4_lds);
+    const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int8_t *__restrict__ cw = conf_slice + (long)w * conf_stride;
+    const int myc = (FULL || lane < nsites) ? (int)cw[site0 + (FULL ? lane : min(lane, nsites - 1))] : 1;
+    const unsigned long long cbits = __ballot(myc > 0);
+    const WalkerRng rs = rngs[w];
+    double uvec;  // lane k: the k-th uniform this chunk consumes, whichever site consumes it (DQMC.jl:573)
+    {
+        const unsigned long long d = rs.draw + (unsigned long long)lane;
+        uvec = rs.uniforms ? (d < rs.n_uniforms ? rs.uniforms[d] : 2.0) : philox_uniform(rs.seed, d);
+    }
+    if (tid < 64) {
+        sm.step[tid] = 0;
+        for (int b = 0; b < NB; ++b) sm.xs[b][tid] = 0.0;
+    }
+    if (tid < 12) sm.sflag[tid] = 0;
+    if (tid < 4) { sm.acc16[tid] = 0u; sm.neg16[tid] = 0u; sm.ndraw[tid] = 0; sm.exh[tid] = 0; }
+    if (tid == 0) sm.abort = 0;
+    __syncthreads();
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    if (wv == 0) lu4_wave<NB, FULL, 0>(n, Gall, strideG, w, site0, nsites, img_all, sc, cbits, uvec, check_sign);
+    else if (wv == 1) lu4_wave<NB, FULL, 1>(n, Gall, strideG, w, site0, nsites, img_all, sc, cbits, uvec, check_sign);
+    else if (wv == 2) lu4_wave<NB, FULL, 2>(n, Gall, strideG, w, site0, nsites, img_all, sc, cbits, uvec, check_sign);
+    else lu4_wave<NB, FULL, 3>(n, Gall, strideG, w, site0, nsites, img_all, sc, cbits, uvec, check_sign);
+    __syncthreads();
+    const int nblk = (nsites + 15) / 16;
+    if (!FULL) {  // blocks past the end of a short chunk: identity triangles, x = 0 (wave I0 fills block I0)
+        const int I0 = wv, g = lane >> 4, ci = lane & 15;
+        if (I0 >= nblk)
+            for (int b = 0; b < NB; ++b) {
+                double *__restrict__ img = img_all + (long)(w * NB + b) * LU_STRIDE;
+                for (int r = 0; r < 4; ++r) {
+                    const double idv = (4 * r + g == ci) ? 1.0 : 0.0;
+                    for (int Jc = I0 + 1; Jc < 4; ++Jc) {
+                        img[LU_OFF_U + lu_pair(I0, Jc) * LU_TILE + r * 64 + lane] = 0.0;
+                        img[LU_OFF_L + lu_pair(I0, Jc) * LU_TILE + r * 64 + lane] = 0.0;
+                    }
+                    img[LU_OFF_PT + I0 * LU_TILE + r * 64 + lane] = idv;
+                    img[LU_OFF_Q + I0 * LU_TILE + r * 64 + lane] = idv;
+                }
+                if (lane < 16) img[LU_IMG + 16 * I0 + lane] = 0.0;
+            }
+    }
+    if (wv == 0) {
+        const unsigned long long accbits = (unsigned long long)sm.acc16[0] | ((unsigned long long)sm.acc16[1] << 16) |
+                                           ((unsigned long long)sm.acc16[2] << 32) | ((unsigned long long)sm.acc16[3] << 48);
+        if (lane < nsites && ((accbits >> lane) & 1ull)) cw[site0 + lane] = (int8_t)(-myc);
+        if (lane == 0) {
+            rngs[w].draw = rs.draw + (unsigned long long)sm.ndraw[nblk - 1];
+            if (sm.exh[nblk - 1]) rngs[w].exhausted = 1;
+            stats[w].prop_local += nsites;
+            stats[w].acc_local += __popcll(accbits);
+            if (sm.abort) atomicOr(errflag, 2);
+            if (NB == 2)  // sign-problem statistics in site order (DQMC.jl:560-566)
+                for (int s = 0; s < nsites; ++s)
+                    if ((sm.neg16[s >> 4] >> (s & 15)) & 1u) magstats_push(stats[w].negative_probability, sm.negv[s]);
+        }
+    }
+}
+
 hipError_t launch_sweep_lu(int n, int nb, int n_walkers, const double *G, long strideG, int8_t *conf_slice,
                            long conf_stride, int site0, int nsites, double *img, SweepConsts sc, WalkerRng *rng,
-                           DevStats *stats, int check_sign, hipStream_t s, hipEvent_t start, hipEvent_t stop)
+                           DevStats *stats, int check_sign, int *errflag, hipStream_t s, hipEvent_t start,
+                           hipEvent_t stop)
 {
     if (nsites < 1 || nsites > 64 || site0 < 0 || site0 + nsites > n || nb < 1 || nb > 2) return hipErrorInvalidValue;
-    dim3 grid(n_walkers), block(64);
     const bool full = nsites == 64;
+    static const bool one_wave = getenv("DQMC_SWEEP_LU1") != nullptr;  // single-wave elimination (A/B measurements)
+    if (one_wave) {
+        dim3 grid(n_walkers), block(64);
 #define LU_LAUNCH(NBV, FL)                                                                                        \
     hipExtLaunchKernelGGL((sweep_lu_kernel<NBV, FL>), grid, block, 0, s, start, stop, 0, n, G, strideG, conf_slice, \
                           conf_stride, site0, nsites, img, sc, rng, stats, check_sign)
-    if (nb == 1) { if (full) LU_LAUNCH(1, true); else LU_LAUNCH(1, false); }
-    else { if (full) LU_LAUNCH(2, true); else LU_LAUNCH(2, false); }
+        if (nb == 1) { if (full) LU_LAUNCH(1, true); else LU_LAUNCH(1, false); }
+        else { if (full) LU_LAUNCH(2, true); else LU_LAUNCH(2, false); }
 #undef LU_LAUNCH
+        return hipGetLastError();
+    }
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    static unsigned attr_mask = 0;  // per device (function attributes are per device)
+    if (!(attr_mask & (1u << dev))) {
+        (void)hipFuncSetAttribute((const void *)sweep_lu4_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lu4Smem<1>));
+        (void)hipFuncSetAttribute((const void *)sweep_lu4_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lu4Smem<1>));
+        (void)hipFuncSetAttribute((const void *)sweep_lu4_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lu4Smem<2>));
+        (void)hipFuncSetAttribute((const void *)sweep_lu4_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lu4Smem<2>));
+        attr_mask |= 1u << dev;
+    }
+    dim3 grid(n_walkers), block(256);
+#define LU4_LAUNCH(NBV, FL)                                                                                          \
+    hipExtLaunchKernelGGL((sweep_lu4_kernel<NBV, FL>), grid, block, sizeof(Lu4Smem<NBV>), s, start, stop, 0, n, G, strideG, \
+                          conf_slice, conf_stride, site0, nsites, img, sc, rng, stats, check_sign, errflag)
+    if (nb == 1) { if (full) LU4_LAUNCH(1, true); else LU4_LAUNCH(1, false); }
+    else { if (full) LU4_LAUNCH(2, true); else LU4_LAUNCH(2, false); }
+#undef LU4_LAUNCH
     return hipGetLastError();
 }
 
@@ -265,7 +651,9 @@ hipError_t launch_sweep_lu(int n, int nb, int n_walkers, const double *G, long s
 // G_out[t][t'] = G_in[t][t'] + sum_s T'[s][t] G_in[site0 + s][t'] for one 64 x 64 tile; wave w owns the 16 rows
 // t = m0 + 16 w .. and computes T' for them (two block-triangular solves, see the file header).
 constexpr int FL_LDR = 66;  // row stride of the R0 tile in LDS (doubles): ci * 66 + g hits 32 distinct 8-byte slots
-template <bool FULL>
+// NT = number of 16-wide column tiles per wave: the workgroup covers 64 rows x 16 NT columns (the triangular solves
+// of a row tile are repeated by every workgroup of that row, so wider is cheaper: NT = 8 when n % 128 == 0).
+template <bool FULL, int NT>
 __global__ __launch_bounds__(256) void sweep_flush_lu_kernel(int n, int n_units, const double *__restrict__ Gin_all,
                                                             double *__restrict__ Gout_all, long strideG, int site0,
                                                             int nsites, const double *__restrict__ img_all,
@@ -274,13 +662,13 @@ __global__ __launch_bounds__(256) void sweep_flush_lu_kernel(int n, int n_units,
     extern __shared__ __attribute__((aligned(16))) double fsm[];
     double *img = fsm;                 // [LU_IMG + 64]
     double *xs = fsm + LU_IMG;
-    double *Rl = fsm + LU_STRIDE;      // [64 t'][FL_LDR]: R0[s][t'] at Rl[t' * FL_LDR + s]
+    double *Rl = fsm + LU_STRIDE;      // [16 NT t'][FL_LDR]: R0[s][t'] at Rl[t' * FL_LDR + s]
     const int bid = blockIdx.x, xcd = bid & 7, seq = bid >> 3;
     const int T = tiles_m * tiles_n;
     const int unit = (seq / T) * 8 + xcd;
     if (unit >= n_units) return;
     const int tile = seq % T;
-    const int m0 = (tile % tiles_m) * 64, n0 = (tile / tiles_m) * 64;
+    const int m0 = (tile % tiles_m) * 64, n0 = (tile / tiles_m) * (16 * NT);
     const double *__restrict__ Gin = Gin_all + (long)unit * strideG;
     double *__restrict__ Gout = Gout_all + (long)unit * strideG;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, ci = lane & 15;
@@ -288,9 +676,9 @@ __global__ __launch_bounds__(256) void sweep_flush_lu_kernel(int n, int n_units,
     const int tq = FULL ? t : min(t, n - 1);
 
     // the tile of G itself first (the kernel is bound by this read-modify-write)
-    d4 acc[4];
+    d4 acc[NT];
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt)
+    for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int tp = n0 + 16 * jt + 4 * r + g;
@@ -314,10 +702,11 @@ __global__ __launch_bounds__(256) void sweep_flush_lu_kernel(int n, int n_units,
         double2 *dst = reinterpret_cast<double2 *>(img);
         for (int i = tid; i < LU_STRIDE / 2; i += 256) dst[i] = src[i];
     }
-    // R0 tile: thread -> column t' = tid / 4, 16 consecutive s
-    {
-        const int tp = n0 + (tid >> 2), s0 = (tid & 3) * 16;
-        double *d = Rl + (tid >> 2) * FL_LDR + s0;
+    // R0 tile: thread -> column t' = pass * 64 + tid / 4, 16 consecutive s
+#pragma unroll
+    for (int pass = 0; pass < NT / 4; ++pass) {
+        const int tl = pass * 64 + (tid >> 2), tp = n0 + tl, s0 = (tid & 3) * 16;
+        double *d = Rl + tl * FL_LDR + s0;
         if (FULL) {
             const double2 *q = reinterpret_cast<const double2 *>(Gin + (long)n * tp + site0 + s0);
 #pragma unroll
@@ -368,11 +757,11 @@ __global__ __launch_bounds__(256) void sweep_flush_lu_kernel(int n, int n_units,
         for (int q = 0; q < 4; ++q) {
             const int sk = 16 * K + 4 * q + g;
 #pragma unroll
-            for (int jt = 0; jt < 4; ++jt)
+            for (int jt = 0; jt < NT; ++jt)
                 acc[jt] = MFMA(Rl[(16 * jt + ci) * FL_LDR + sk], tt[K][q], acc[jt]);
         }
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt)
+    for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int tp = n0 + 16 * jt + 4 * r + g;
@@ -383,26 +772,29 @@ __global__ __launch_bounds__(256) void sweep_flush_lu_kernel(int n, int n_units,
 hipError_t launch_sweep_flush_lu(int n, int n_units, const double *Gin, double *Gout, long strideG, int site0,
                                  int nsites, const double *img, hipStream_t s, hipEvent_t start, hipEvent_t stop)
 {
-    const int tm = (n + 63) / 64, tn = tm;
+    const bool wide = n % 128 == 0;
+    const int nt = wide ? 8 : 4;
+    const int tm = (n + 63) / 64, tn = (n + 16 * nt - 1) / (16 * nt);
     const int groups = (n_units + 7) / 8;
-    const size_t lds = ((size_t)LU_STRIDE + 64 * FL_LDR) * sizeof(double);
+    const size_t lds = ((size_t)LU_STRIDE + 16 * nt * FL_LDR) * sizeof(double);
     const bool full = (n % 64 == 0) && nsites == 64;
     int dev = 0;
     (void)hipGetDevice(&dev);
     static unsigned attr_mask = 0;  // per device (function attributes are per device)
     if (!(attr_mask & (1u << dev))) {
-        (void)hipFuncSetAttribute((const void *)sweep_flush_lu_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
-        (void)hipFuncSetAttribute((const void *)sweep_flush_lu_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
+        const int big = (int)(((size_t)LU_STRIDE + 128 * FL_LDR) * sizeof(double));
+        (void)hipFuncSetAttribute((const void *)sweep_flush_lu_kernel<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+        (void)hipFuncSetAttribute((const void *)sweep_flush_lu_kernel<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+        (void)hipFuncSetAttribute((const void *)sweep_flush_lu_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+        (void)hipFuncSetAttribute((const void *)sweep_flush_lu_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
         attr_mask |= 1u << dev;
     }
-    if (full)
-        hipExtLaunchKernelGGL(sweep_flush_lu_kernel<true>, dim3(groups * 8 * tm * tn), dim3(256), lds, s, start, stop, 0, n,
-                              n_units, Gin, Gout, strideG, site0, nsites, img, tm, tn);
-    else
-        hipExtLaunchKernelGGL(sweep_flush_lu_kernel<false>, dim3(groups * 8 * tm * tn), dim3(256), lds, s, start, stop, 0,
-                              n, n_units, Gin, Gout, strideG, site0, nsites, img, tm, tn);
+#define FL_LAUNCH(FU, NTV)                                                                                          \
+    hipExtLaunchKernelGGL((sweep_flush_lu_kernel<FU, NTV>), dim3(groups * 8 * tm * tn), dim3(256), lds, s, start, stop, 0, \
+                          n, n_units, Gin, Gout, strideG, site0, nsites, img, tm, tn)
+    if (wide) { if (full) FL_LAUNCH(true, 8); else FL_LAUNCH(false, 8); }
+    else { if (full) FL_LAUNCH(true, 4); else FL_LAUNCH(false, 4); }
+#undef FL_LAUNCH
     return hipGetLastError();
 }
 

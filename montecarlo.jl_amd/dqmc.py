@@ -366,8 +366,55 @@ class DQMC:
         self._c(lib().dqmc_get_stats(self._h, walker, C.byref(st)))
         return DQMCAnalysis(st)
 
+    def analysis_sum(self):
+        """(prop_local, acc_local) summed over the walkers of this handle"""
+        tot = [0, 0]
+        for w in range(self.n_walkers):
+            a = self.analysis(w)
+            tot[0] += a.prop_local
+            tot[1] += a.acc_local
+        return tuple(tot)
+
     def accumulate_greens(self):
         self._c(lib().dqmc_accumulate_greens(self._h))
+
+    # ---- measurement reduction over ranks (inside the library: RCCL all-reduce on the engine's stream)
+    def reduce(self, comm=None):
+        """dqmc_reduce: every accumulator and the DQMCAnalysis counters summed (max / min for the magnitude
+        statistics) over all ranks of `comm` (a sharding.Communicator, or None for this handle alone)"""
+        self._c(lib().dqmc_reduce(self._h, comm.handle if comm is not None else None))
+
+    def reduced_analysis(self):
+        st = _lib.Stats()
+        self._c(lib().dqmc_get_reduced_stats(self._h, C.byref(st)))
+        return DQMCAnalysis(st)
+
+    def reduce_size(self):
+        n = C.c_size_t()
+        self._c(lib().dqmc_reduce_size(self._h, C.byref(n)))
+        return n.value
+
+    def reduce_export(self):
+        """packed [sums | 2 maxima | 2 minima] for a host-side collective"""
+        out = np.zeros(self.reduce_size())
+        self._c(lib().dqmc_reduce_export(self._h, dptr(out)))
+        return out
+
+    def reduce_import(self, buf):
+        buf = np.ascontiguousarray(buf, dtype=np.float64)
+        self._c(lib().dqmc_reduce_import(self._h, dptr(buf)))
+
+    def reduce_host(self, dist):
+        """the same reduction through a torch.distributed process group on host buffers (gloo): what a host with
+        its own collective (MPI from Julia) does around dqmc_reduce_export / dqmc_reduce_import"""
+        import torch
+        buf = torch.from_numpy(self.reduce_export())
+        n = buf.numel() - 4
+        if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(buf[:n], op=dist.ReduceOp.SUM)
+            dist.all_reduce(buf[n:n + 2], op=dist.ReduceOp.MAX)
+            dist.all_reduce(buf[n + 2:], op=dist.ReduceOp.MIN)
+        self.reduce_import(buf.numpy())
 
     def reset_accumulators(self):
         self._c(lib().dqmc_reset_accumulators(self._h))
@@ -403,6 +450,14 @@ class DQMC:
 
     def accumulate_correlations(self):
         self._c(lib().dqmc_accumulate_correlations(self._h))
+
+    def correlations_raw(self):
+        """the raw sums [cdc][sdc_x][sdc_y][sdc_z][mx][my][mz][count] (layout of include/dqmc_hip.h)"""
+        n = C.c_size_t()
+        self._c(lib().dqmc_correlations_size(self._h, C.byref(n)))
+        out = np.zeros(n.value)
+        self._c(lib().dqmc_get_correlations(self._h, dptr(out)))
+        return out
 
     def correlations(self):
         """-> dict of means: CDC, SDCx, SDCy, SDCz per direction; Mx, My, Mz per site; count"""

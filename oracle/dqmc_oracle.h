@@ -42,6 +42,8 @@ int orc_build_checkerboard(int n_sites, int n_bonds, const int64_t *bonds,
 void orc_hopping_square(int L, double t, double mu, double *T /* n x n */);
 
 /* ---- linalg: src/linalg/general.jl:7-166 */
+/* timing-only: route the four dense products to a Fortran-interface dgemm (NULL restores the literal loops) */
+void orc_set_dgemm_hook(void *fn);
 void orc_vmul_nn(int n, double *C, const double *A, const double *B);
 void orc_vmul_nt(int n, double *C, const double *A, const double *B); /* A * B'  */
 void orc_vmul_tn(int n, double *C, const double *A, const double *B); /* A' * B  */

@@ -89,6 +89,8 @@ def lib(path=None):
         for name in ("orc_vmul_nn", "orc_vmul_nt", "orc_vmul_tn", "orc_vmul_tt", "orc_vmul_nd", "orc_vmul_dn"):
             getattr(L, name).argtypes = [C.c_int, dp, dp, dp]
             getattr(L, name).restype = None
+        L.orc_set_dgemm_hook.argtypes = [C.c_void_p]
+        L.orc_set_dgemm_hook.restype = None
         L.orc_rdivp.argtypes = [C.c_int, dp, dp, dp, ip]
         L.orc_udt_pivot.argtypes = [C.c_int, dp, dp, dp, ip, dp, C.c_int]
         L.orc_calculate_greens.argtypes = [C.c_int, dp, dp, dp, dp, dp, dp, dp, ip, dp]
@@ -96,6 +98,27 @@ def lib(path=None):
                                     C.POINTER(IsingResult)]
         _lib = L
     return _lib
+
+
+def use_openblas_dgemm(on=True):
+    """Timing-only (bench.py "strong CPU" leg): route the oracle's four dense products to the dgemm of the BLAS that
+    scipy links (OpenBLAS in this image), through scipy.linalg.cython_blas's C-API capsule.  Returns False if the
+    capsule is not available.  Never used by the parity tests."""
+    if not on:
+        lib().orc_set_dgemm_hook(None)
+        return True
+    try:
+        import scipy.linalg.cython_blas as cb
+        cap = cb.__pyx_capi__["dgemm"]
+        C.pythonapi.PyCapsule_GetName.restype = C.c_char_p
+        C.pythonapi.PyCapsule_GetName.argtypes = [C.py_object]
+        C.pythonapi.PyCapsule_GetPointer.restype = C.c_void_p
+        C.pythonapi.PyCapsule_GetPointer.argtypes = [C.py_object, C.c_char_p]
+        ptr = C.pythonapi.PyCapsule_GetPointer(cap, C.pythonapi.PyCapsule_GetName(cap))
+    except Exception:
+        return False
+    lib().orc_set_dgemm_hook(ptr)
+    return True
 
 
 def _dp(a):
