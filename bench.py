@@ -55,6 +55,26 @@ def flops_per_sweep(n, nb, M, K, acc_rate):
     return dict(total=gemm + qr + trsm + rank1, gemm=gemm, qr=qr, trsm=trsm, flush=rank1, sweep=0.0, misc=0.0)
 
 
+def effective_cores():
+    """host cores this process may actually use: the cgroup CPU quota when there is one (a GPU box hands out a share of
+    its cores per GPU), else the affinity mask"""
+    aff = len(os.sched_getaffinity(0))
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            return max(1, min(aff, int(float(q) / float(p)))), aff
+    except Exception:
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            return max(1, min(aff, q // p)), aff
+    except Exception:
+        pass
+    return aff, aff
+
+
 def cpu_baseline(cfg, n_threads, sweeps_each, use_blas, partial_updates=None):
     """Oracle chains, one per host core (the reference is one chain per core by construction).  Returns
     (walker-sweeps/s, seconds, description of the sample)."""
@@ -116,8 +136,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sweeps", type=int, default=5)
     ap.add_argument("--no-kernel-timing", action="store_true", help="no HIP events on the launches of the timed region")
+    ap.add_argument("--cpu-leg", choices=("port", "blas"), default=None,
+                    help="internal: run only this CPU baseline leg (child process, never touches the GPU)")
+    ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
+    if args.cpu_leg:  # child process of the GPU run: isolates the BLAS runtime (and any crash of it) from the bench
+        r = cpu_baseline(cfg, args.cpu_threads, args.cpu_sweeps, args.cpu_leg == "blas", 20 if args.config == 5 else None)
+        print(json.dumps(None if r is None else {"value": r[0], "secs": r[1], "what": r[2]}))
+        return
     steps = args.steps if args.steps is not None else cfg["steps"]
     warmup = args.warmup if args.warmup is not None else cfg["warmup"]
 
@@ -168,9 +195,6 @@ def main():
     for _ in range(warmup):
         mc.sweep(1)
     a0 = mc.analysis_sum()
-    timing = not args.no_kernel_timing
-    if timing:
-        mc.timing_enable(True)   # events ride on the launches of the timed region; drained after the timer stops
     barrier()
     t0 = time.perf_counter()
     for i in range(steps):
@@ -180,14 +204,24 @@ def main():
             mc.reduce(comm)
     barrier()
     dt = time.perf_counter() - t0
-    tim = mc.timing() if timing else {}
-    if timing:
-        mc.timing_enable(False)
     a1 = mc.analysis_sum()
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda:%d" % local_rank)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    # Kernel pass: the same K steps once more with HIP events attached to every launch (drained after its own timer
+    # stops).  Kept apart from the region `value` is taken from, because the events themselves cost ~4 us per launch
+    # (about 2900 launches per sweep); the family times add up to less than THIS pass's time per step.
+    tim, kp_ms = {}, None
+    if not args.no_kernel_timing:
+        mc.timing_enable(True)
+        barrier()
+        t1 = time.perf_counter()
+        mc.sweep(steps)
+        barrier()
+        kp_ms = (time.perf_counter() - t1) / steps * 1e3
+        tim = mc.timing()
+        mc.timing_enable(False)
     acc_rate = (a1[1] - a0[1]) / max(1, a1[0] - a0[0])
 
     value = total_walkers * steps / dt
@@ -209,7 +243,7 @@ def main():
     for fam, (ms, launches) in sorted(tim.items(), key=lambda kv: -kv[1][0]):
         ms_sweep = ms / steps
         sum_ms += ms_sweep
-        ent = {"family": fam, "ms_per_sweep": ms_sweep, "share_of_step": ms_sweep / ms_per_step if ms_per_step else 0.0,
+        ent = {"family": fam, "ms_per_sweep": ms_sweep, "share_of_kernel_pass": ms_sweep / kp_ms if kp_ms else 0.0,
                "launches_per_sweep": launches / steps, "avg_launch_us": ms * 1e3 / max(1, launches),
                "bound": bounds.get(fam, "latency"), "note": notes.get(fam, "")}
         fl = F.get(fam, 0.0)
@@ -247,26 +281,43 @@ def main():
                                    "(%.3f GFLOP at the measured acceptance) x walker-sweeps/s per GPU" % (F["total"] / 1e9),
                      "traffic": traffic,
                      "traffic_note": "HBM bytes of one full 256^3 x 32 gemm_kernel launch, profiles/*_pmc_gemm.json",
-                     "kernels": kernels, "kernel_ms_sum": sum_ms,
+                     "kernels": kernels, "kernel_ms_sum": sum_ms, "kernel_pass_ms_per_step": kp_ms,
+                     "kernel_pass_note": "family times from HIP events attached to the launches of a second region of "
+                                         "the same K steps; ms_per_step / value come from the event-free region",
                      "dominant_kernel": None if dom is None else {k: dom.get(k) for k in (
                          "family", "avg_launch_us", "launches_per_sweep", "bound", "achieved_tflops",
                          "frac_of_fp64_peak")}},
     }
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
-        cores = len(os.sched_getaffinity(0))
-        partial = 20 if args.config == 5 else None
-        r = cpu_baseline(cfg, cores, args.cpu_sweeps, False, partial)
-        out["cpu_baseline"] = {"value": r[0], "unit": "walker-sweeps/s", "cores": cores, "nproc": os.cpu_count(),
-                               "kind": "port",
-                               "sample": "%d oracle chains (one per core, all cores of the box) x %s of the same "
-                                         "workload, %.1f s; restatement of MonteCarlo.jl's algorithm, not the Julia "
-                                         "package" % (cores, r[2], r[1])}
-        rb = cpu_baseline(cfg, cores, args.cpu_sweeps, True, partial)
-        if rb is not None:
-            out["cpu_baseline"]["strong_cpu"] = {
-                "value": rb[0], "unit": "walker-sweeps/s", "cores": cores,
-                "sample": "same chains with the dense products routed to OpenBLAS dgemm (scipy's BLAS, 1 thread per "
-                          "chain), %s, %.1f s; QR / rank-1 updates stay literal" % (rb[2], rb[1])}
+        import subprocess
+        cores, visible = effective_cores()
+
+        def leg(kind, threads):
+            try:
+                p = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", str(args.config), "--cpu-leg",
+                                    kind, "--cpu-threads", str(threads), "--cpu-sweeps", str(args.cpu_sweeps)],
+                                   stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600)
+                return json.loads(p.stdout.decode().strip().splitlines()[-1])
+            except Exception:
+                return None
+
+        r = leg("port", cores)
+        if r is not None:
+            out["cpu_baseline"] = {"value": r["value"], "unit": "walker-sweeps/s", "cores": cores,
+                                   "nproc": visible, "kind": "port",
+                                   "cores_note": "cores = cgroup CPU quota of this box (cpu.max); nproc = visible CPUs",
+                                   "sample": "%d oracle chains (one per usable core) x %s of the same "
+                                             "workload, %.1f s; restatement of MonteCarlo.jl's algorithm, not the "
+                                             "Julia package" % (cores, r["what"], r["secs"])}
+            bl = min(cores, 64)  # the image's OpenBLAS serves at most 128 concurrent callers
+            rb = leg("blas", bl)
+            if rb is not None:
+                out["cpu_baseline"]["strong_cpu"] = {
+                    "value": rb["value"] * cores / bl, "unit": "walker-sweeps/s", "cores": cores,
+                    "measured_on_cores": bl, "measured_value": rb["value"],
+                    "sample": "%d chains with the dense products routed to OpenBLAS dgemm (scipy's BLAS, 1 thread per "
+                              "chain), %s, %.1f s; QR / rank-1 updates stay literal; scaled linearly to %d cores"
+                              % (bl, rb["what"], rb["secs"], cores)}
     if rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
