@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdqmc_hip.so")
+# DQMC_HIP_LIB selects another build of the same library (diagnostic / A-B builds), never a fallback
+LIB_PATH = os.environ.get("DQMC_HIP_LIB") or os.path.join(_HERE, "libdqmc_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "dqmc_hip.h")
 
 OK, ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_STATE, ERR_RNG = 0, -1, -2, -3, -4, -5

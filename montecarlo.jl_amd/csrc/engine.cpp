@@ -49,7 +49,7 @@ struct dqmc_handle {
     int *pivot = nullptr;
     double *sU = nullptr, *sVT = nullptr;
     double *greens_alt = nullptr, *lu_img = nullptr;  // decide / apply sweep (sweep_lu.hip)
-    bool sweep_lu = true;
+    bool sweep_lu = true, sweep_fused = true;
     WalkerRng *rng = nullptr;
     DevStats *stats = nullptr;
     std::vector<double *> uniforms;  // per walker device arrays
@@ -528,13 +528,38 @@ static int sweep_spatial(dqmc_handle *h)
     int8_t *cslice = h->conf + (long)(l - 1) * h->N;
     h->conf_version++;
     if (h->sweep_lu) {
-        // decide on the 64 x 64 block (one wave per walker), then apply the chunk out of place with MFMA
+        // decide on the 64 x 64 block (four waves per walker), apply the chunk out of place with MFMA
         double *cur = h->greens, *alt = h->greens_alt;
+        const size_t istr = (size_t)h->units * sweep_lu_image_doubles();
+        const long cstr = (long)h->N * h->M;
+        hipEvent_t a, b;
+        if (h->sweep_fused && h->n % 64 == 0 && h->N >= 128) {
+            // the elimination of chunk c runs beside the flush of chunk c - 1 (one launch per chunk boundary)
+            const int nc = h->N / 64;
+            timing_events(h, &a, &b);
+            HIPCHK(launch_sweep_lu(h->n, h->nb, h->W, cur, h->nn, cslice, cstr, 0, 64, h->lu_img, h->sc, h->rng, h->stats,
+                                   h->p.check_sign_problem, h->qr_ws.errflag, h->stream, a, b));
+            CHK(timing_push(h, a, b, DQMC_K_SWEEP));
+            for (int c = 1; c < nc; ++c) {
+                timing_events(h, &a, &b);
+                HIPCHK(launch_sweep_fused(h->n, h->nb, h->W, cur, alt, h->nn, cslice, cstr, 64 * c, 64 * (c - 1),
+                                          h->lu_img + (size_t)(c & 1) * istr, h->lu_img + (size_t)((c - 1) & 1) * istr, h->sc,
+                                          h->rng, h->stats, h->p.check_sign_problem, h->qr_ws.errflag, h->stream, a, b));
+                CHK(timing_push(h, a, b, DQMC_K_SWEEP));
+                std::swap(cur, alt);
+            }
+            timing_events(h, &a, &b);
+            HIPCHK(launch_sweep_flush_lu(h->n, h->units, cur, alt, h->nn, 64 * (nc - 1), 64,
+                                         h->lu_img + (size_t)((nc - 1) & 1) * istr, h->stream, a, b));
+            CHK(timing_push(h, a, b, DQMC_K_FLUSH));
+            std::swap(cur, alt);
+            if (cur != h->greens) std::swap(h->greens, h->greens_alt);
+            return 0;
+        }
         for (int site0 = 0; site0 < h->N; site0 += 64) {
             const int ns = std::min(64, h->N - site0);
-            hipEvent_t a, b;
             timing_events(h, &a, &b);
-            HIPCHK(launch_sweep_lu(h->n, h->nb, h->W, cur, h->nn, cslice, (long)h->N * h->M, site0, ns, h->lu_img, h->sc,
+            HIPCHK(launch_sweep_lu(h->n, h->nb, h->W, cur, h->nn, cslice, cstr, site0, ns, h->lu_img, h->sc,
                                    h->rng, h->stats, h->p.check_sign_problem, h->qr_ws.errflag, h->stream, a, b));
             CHK(timing_push(h, a, b, DQMC_K_SWEEP));
             timing_events(h, &a, &b);
@@ -631,6 +656,10 @@ int dqmc_create(const dqmc_params *p, dqmc_handle **out)
     h->nn = (long)h->n * h->n;
     h->kd = sweep_kd(h->n, h->nb);
     h->sweep_lu = !sweep_old;
+    // elimination of chunk c beside the flush of chunk c - 1 in one launch: correct, but measured SLOWER than the
+    // two separate launches (the elimination then has to apply the previous chunk to its own block first and shares
+    // its CU's matrix pipes with flush workgroups); kept for experiments only
+    h->sweep_fused = getenv("DQMC_SWEEP_FUSED") != nullptr;
     // lambda = acosh(exp(U*dtau/2)) (Attractive.jl:103,118; Repulsive.jl:116,138)
     h->lambda = std::acosh(std::exp(0.5 * p->U * p->delta_tau));
     h->epl = std::exp(h->lambda);
@@ -688,7 +717,7 @@ int dqmc_create(const dqmc_params *p, dqmc_handle **out)
     CCHK(dalloc(h, &h->sU, (size_t)h->units * h->n * h->kd));
     CCHK(dalloc(h, &h->sVT, (size_t)h->units * h->n * h->kd));
     CCHK(dalloc(h, &h->greens_alt, un));
-    CCHK(dalloc(h, &h->lu_img, (size_t)h->units * sweep_lu_image_doubles()));
+    CCHK(dalloc(h, &h->lu_img, 2 * (size_t)h->units * sweep_lu_image_doubles()));
     CCHK(dalloc(h, &h->rng, (size_t)h->W));
     CCHK(dalloc(h, &h->stats, (size_t)h->W));
     {

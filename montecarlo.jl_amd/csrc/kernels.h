@@ -171,6 +171,11 @@ hipError_t launch_sweep_lu(int n, int nb, int n_walkers, const double *G, long s
                            long conf_stride, int site0, int nsites, double *img, SweepConsts sc, WalkerRng *rng,
                            DevStats *stats, int check_sign, int *errflag, hipStream_t s,
                            hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
+// elimination of chunk `site0` beside the flush of the previous chunk `site0p` (one launch; n % 64 == 0)
+hipError_t launch_sweep_fused(int n, int nb, int n_walkers, const double *Gin, double *Gout, long strideG,
+                              int8_t *conf_slice, long conf_stride, int site0, int site0p, double *img,
+                              const double *imgp, SweepConsts sc, WalkerRng *rng, DevStats *stats, int check_sign,
+                              int *errflag, hipStream_t s, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
 hipError_t launch_sweep_flush_lu(int n, int n_units, const double *Gin, double *Gout, long strideG, int site0,
                                  int nsites, const double *img, hipStream_t s, hipEvent_t start = nullptr,
                                  hipEvent_t stop = nullptr);

@@ -306,11 +306,25 @@ __device__ __forceinline__ double lu4_rcp(double r)
 }
 
 extern __shared__ __attribute__((aligned(16))) double lu4_lds[];
+#ifdef LU4_STAMPS  // diagnostic build only (tools/lu4_stamps.py): cycle stamps of walker 0 into a buffer of their own
+__device__ long long *lu4_stamp_ptr = nullptr;
+#define LU4_STAMP(idx)                                                                       \
+    do {                                                                                     \
+        if (w == 0 && (threadIdx.x & 63) == 0 && lu4_stamp_ptr) lu4_stamp_ptr[(idx)] = (long long)__builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define LU4_STAMP(idx) do { } while (0)
+#endif
 // one function per wave role (not inlined into each other: each gets its own register allocation)
-template <int NB, bool FULL, int J>
+// PRO: the previous chunk (sites site0p ..+63, images imgp_all) has not been applied to G yet: the wave adds its
+// contribution T R0 to its tiles itself (the same two block-triangular solves and K = 64 products as
+// sweep_flush_lu_kernel, for the 16 rows / columns of its block column), so that this elimination can run beside the
+// flush of the previous chunk instead of behind it.
+template <int NB, bool FULL, bool PRO, int J>
 __device__ __noinline__ void lu4_wave(int n, const double *__restrict__ Gall, long strideG, int w, int site0,
                                       int nsites, double *__restrict__ img_all, const SweepConsts &sc,
-                                      unsigned long long cbits_v, double uvec, int check_sign)
+                                      unsigned long long cbits_v, double uvec, int check_sign, int site0p,
+                                      const double *__restrict__ imgp_all)
 {
     Lu4Smem<NB> &sm = *reinterpret_cast<Lu4Smem<NB> *>(lu4_lds);
     const int lane = threadIdx.x & 63, g = lane >> 4, ci = lane & 15;
@@ -338,6 +352,101 @@ __device__ __noinline__ void lu4_wave(int n, const double *__restrict__ Gall, lo
                 }
             }
     }
+    if (PRO) {
+        // LDS scratch aliased onto the (not yet used) step ring: R0 block [64 t'][66] and the T' tiles of waves 0..2
+        double *Rl = reinterpret_cast<double *>(&sm.aST[0][0][0]);
+        double *ttx = Rl + 64 * 66;
+        const int tid = threadIdx.x;
+#pragma unroll 1
+        for (int b = 0; b < NB; ++b) {
+            const double *__restrict__ Gin = Gall + (long)(w * NB + b) * strideG;
+            const double *__restrict__ imgp = imgp_all + (long)(w * NB + b) * LU_STRIDE;
+            const int t = site0 + 16 * J + ci;
+            d4 az[4];
+#pragma unroll
+            for (int Jb = 0; Jb < 4; ++Jb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) az[Jb][r] = Gin[t + (long)n * (site0p + 16 * Jb + 4 * r + g)];
+            {   // R0 block: thread -> column t' = tid / 4 of this chunk, 16 consecutive sites of the previous one
+                const int tl = tid >> 2, s0 = (tid & 3) * 16;
+                const double2 *q = reinterpret_cast<const double2 *>(Gin + (long)n * (site0 + tl) + site0p + s0);
+                double2 *d = reinterpret_cast<double2 *>(Rl + tl * 66 + s0);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) d[i] = q[i];
+            }
+            // all 80 operands of the two triangles requested at once (from L2), before the dependent MFMA chain
+            double opU[6][4], opL[6][4], opP[4][4], opQ[4][4], xr[4][4];
+#pragma unroll
+            for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    opU[pr][q] = imgp[LU_OFF_U + pr * LU_TILE + q * 64 + lane];
+                    opL[pr][q] = imgp[LU_OFF_L + pr * LU_TILE + q * 64 + lane];
+                }
+#pragma unroll
+            for (int Jb = 0; Jb < 4; ++Jb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    opP[Jb][q] = imgp[LU_OFF_PT + Jb * LU_TILE + q * 64 + lane];
+                    opQ[Jb][q] = imgp[LU_OFF_Q + Jb * LU_TILE + q * 64 + lane];
+                    xr[Jb][q] = imgp[LU_IMG + 16 * Jb + 4 * q + g];
+                }
+            d4 xz[4], tt[4];
+#pragma unroll
+            for (int Jb = 0; Jb < 4; ++Jb) {
+#pragma unroll
+                for (int K = 0; K < Jb; ++K)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) az[Jb] = MFMA(opU[lu_pair(K, Jb)][q], xz[K][q], az[Jb]);
+                d4 z = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) z = MFMA(opP[Jb][q], az[Jb][q], z);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xz[Jb][r] = z[r] * xr[Jb][r];
+            }
+#pragma unroll
+            for (int Jb = 3; Jb >= 0; --Jb) {
+                d4 a = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int K = Jb + 1; K < 4; ++K)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) a = MFMA(opL[lu_pair(Jb, K)][q], tt[K][q], a);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a[r] = xz[Jb][r] + xr[Jb][r] * a[r];
+                d4 o = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o = MFMA(opQ[Jb][q], a[q], o);
+                tt[Jb] = o;
+            }
+            if (J < 3) {
+#pragma unroll
+                for (int K = 0; K < 4; ++K)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) ttx[((J * 4 + K) * 4 + q) * 64 + lane] = tt[K][q];
+            }
+            __syncthreads();  // R0 block and the T' tiles of the other waves are in LDS
+#pragma unroll
+            for (int I = 0; I <= J; ++I)
+#pragma unroll
+                for (int K = 0; K < 4; ++K)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int sk = 16 * K + 4 * q + g;
+                        // S' tile (I, J): rows of G in my block column (my own T'), columns in block I
+                        ST[b][I] = MFMA(Rl[(16 * I + ci) * 66 + sk], tt[K][q], ST[b][I]);
+                        // S tile (I, J): rows in block I (T' of wave I), columns in my block
+                        const double ta = (I == J) ? tt[K][q] : ttx[((I * 4 + K) * 4 + q) * 64 + lane];
+                        S[b][I] = MFMA(ta, Rl[(16 * J + ci) * 66 + sk], S[b][I]);
+                    }
+            __syncthreads();  // scratch is free again (next block / the step ring)
+        }
+        LU4_STAMP(320 + 8 * J + 7);
+    }
+    LU4_STAMP(320 + 8 * J + 0);
+#ifdef LU4_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    LU4_STAMP(320 + 8 * J + 1);
+#endif
     const double g0 = sc.gamma[0], g1 = sc.gamma[1], e0 = sc.ebos[0], e1 = sc.ebos[1];
     const double du0 = sc.dup[0], du1 = sc.dup[1], dd0 = sc.ddn[0], dd1 = sc.ddn[1];
     int lastflag = 0;  // the newest step word seen (carries the draw counter from pivot to pivot)
@@ -375,6 +484,7 @@ __device__ __noinline__ void lu4_wave(int n, const double *__restrict__ Gall, lo
                 const int c = 4 * r0 + ks, s = 16 * I0 + c;
                 if (!FULL && s >= nsites) continue;
                 if (PIV) {
+                    LU4_STAMP(s);
                     const int spin = (int)((cbits >> s) & 1ull);
                     double det, p, xb[NB];
                     if (NB == 1) {  // HubbardModelAttractive.jl:113-127
@@ -464,6 +574,7 @@ __device__ __noinline__ void lu4_wave(int n, const double *__restrict__ Gall, lo
                         v = -1;
                     }
                     if (v > 0) lastflag = v;
+                    LU4_STAMP(64 * (1 + J) + s);
                     if (v > 0 && (v & 3) == 2) {
                         panel_acc |= 1u << ks;
 #pragma unroll
@@ -514,6 +625,7 @@ __device__ __noinline__ void lu4_wave(int n, const double *__restrict__ Gall, lo
             }
         }
         // block row I0 is final: register images for the flush kernel
+        LU4_STAMP(320 + 8 * J + 2 + I0);
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             double *__restrict__ img = img_all + (long)(w * NB + b) * LU_STRIDE;
@@ -541,16 +653,18 @@ __device__ __noinline__ void lu4_wave(int n, const double *__restrict__ Gall, lo
             if (NB == 2 && (lane >> 4) == I0) sm.negv[lane] = negv;
         }
     }
+    LU4_STAMP(320 + 8 * J + 6);
 }
 
-template <int NB, bool FULL>
-__global__ __launch_bounds__(256) void sweep_lu4_kernel(int n, const double *__restrict__ Gall, long strideG,
-                                                       int8_t *__restrict__ conf_slice, long conf_stride, int site0,
-                                                       int nsites, double *__restrict__ img_all, SweepConsts sc,
-                                                       WalkerRng *rngs, DevStats *stats, int check_sign, int *errflag)
+template <int NB, bool FULL, bool PRO>
+__device__ __forceinline__ void lu4_block(int w, int n, const double *__restrict__ Gall, long strideG,
+                                          int8_t *__restrict__ conf_slice, long conf_stride, int site0, int nsites,
+                                          double *__restrict__ img_all, const SweepConsts &sc, WalkerRng *rngs,
+                                          DevStats *stats, int check_sign, int *errflag, int site0p,
+                                          const double *__restrict__ imgp_all)
 {
     Lu4Smem<NB> &sm = *reinterpret_cast<Lu4Smem<NB> *>(lu4_lds);
-    const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int8_t *__restrict__ cw = conf_slice + (long)w * conf_stride;
     const int myc = (FULL || lane < nsites) ? (int)cw[site0 + (FULL ? lane : min(lane, nsites - 1))] : 1;
     const unsigned long long cbits = __ballot(myc > 0);
@@ -565,14 +679,17 @@ __global__ __launch_bounds__(256) void sweep_lu4_kernel(int n, const double *__r
         for (int b = 0; b < NB; ++b) sm.xs[b][tid] = 0.0;
     }
     if (tid < 12) sm.sflag[tid] = 0;
+#ifdef LU4_STAMPS
+    if (w == 0 && tid == 0 && lu4_stamp_ptr) lu4_stamp_ptr[360] = (long long)__builtin_amdgcn_s_memtime();
+#endif
     if (tid < 4) { sm.acc16[tid] = 0u; sm.neg16[tid] = 0u; sm.ndraw[tid] = 0; sm.exh[tid] = 0; }
     if (tid == 0) sm.abort = 0;
     __syncthreads();
     const int wv = __builtin_amdgcn_readfirstlane(wave);
-    if (wv == 0) lu4_wave<NB, FULL, 0>(n, Gall, strideG, w, site0, nsites, img_all, sc, cbits, uvec, check_sign);
-    else if (wv == 1) lu4_wave<NB, FULL, 1>(n, Gall, strideG, w, site0, nsites, img_all, sc, cbits, uvec, check_sign);
-    else if (wv == 2) lu4_wave<NB, FULL, 2>(n, Gall, strideG, w, site0, nsites, img_all, sc, cbits, uvec, check_sign);
-    else lu4_wave<NB, FULL, 3>(n, Gall, strideG, w, site0, nsites, img_all, sc, cbits, uvec, check_sign);
+    if (wv == 0) lu4_wave<NB, FULL, PRO, 0>(n, Gall, strideG, w, site0, nsites, img_all, sc, cbits, uvec, check_sign, site0p, imgp_all);
+    else if (wv == 1) lu4_wave<NB, FULL, PRO, 1>(n, Gall, strideG, w, site0, nsites, img_all, sc, cbits, uvec, check_sign, site0p, imgp_all);
+    else if (wv == 2) lu4_wave<NB, FULL, PRO, 2>(n, Gall, strideG, w, site0, nsites, img_all, sc, cbits, uvec, check_sign, site0p, imgp_all);
+    else lu4_wave<NB, FULL, PRO, 3>(n, Gall, strideG, w, site0, nsites, img_all, sc, cbits, uvec, check_sign, site0p, imgp_all);
     __syncthreads();
     const int nblk = (nsites + 15) / 16;
     if (!FULL) {  // blocks past the end of a short chunk: identity triangles, x = 0 (wave I0 fills block I0)
@@ -602,11 +719,24 @@ __global__ __launch_bounds__(256) void sweep_lu4_kernel(int n, const double *__r
             stats[w].prop_local += nsites;
             stats[w].acc_local += __popcll(accbits);
             if (sm.abort) atomicOr(errflag, 2);
+#ifdef LU4_STAMPS
+            if (w == 0 && lu4_stamp_ptr) lu4_stamp_ptr[361] = (long long)__builtin_amdgcn_s_memtime();
+#endif
             if (NB == 2)  // sign-problem statistics in site order (DQMC.jl:560-566)
                 for (int s = 0; s < nsites; ++s)
                     if ((sm.neg16[s >> 4] >> (s & 15)) & 1u) magstats_push(stats[w].negative_probability, sm.negv[s]);
         }
     }
+}
+
+template <int NB, bool FULL>
+__global__ __launch_bounds__(256) void sweep_lu4_kernel(int n, const double *__restrict__ Gall, long strideG,
+                                                       int8_t *__restrict__ conf_slice, long conf_stride, int site0,
+                                                       int nsites, double *__restrict__ img_all, SweepConsts sc,
+                                                       WalkerRng *rngs, DevStats *stats, int check_sign, int *errflag)
+{
+    lu4_block<NB, FULL, false>(blockIdx.x, n, Gall, strideG, conf_slice, conf_stride, site0, nsites, img_all, sc, rngs,
+                               stats, check_sign, errflag, 0, nullptr);
 }
 
 hipError_t launch_sweep_lu(int n, int nb, int n_walkers, const double *G, long strideG, int8_t *conf_slice,
@@ -654,16 +784,15 @@ constexpr int FL_LDR = 66;  // row stride of the R0 tile in LDS (doubles): ci * 
 // NT = number of 16-wide column tiles per wave: the workgroup covers 64 rows x 16 NT columns (the triangular solves
 // of a row tile are repeated by every workgroup of that row, so wider is cheaper: NT = 8 when n % 128 == 0).
 template <bool FULL, int NT>
-__global__ __launch_bounds__(256) void sweep_flush_lu_kernel(int n, int n_units, const double *__restrict__ Gin_all,
-                                                            double *__restrict__ Gout_all, long strideG, int site0,
-                                                            int nsites, const double *__restrict__ img_all,
-                                                            int tiles_m, int tiles_n)
+__device__ __forceinline__ void flush_lu_body(int bid, int n, int n_units, const double *__restrict__ Gin_all,
+                                              double *__restrict__ Gout_all, long strideG, int site0, int nsites,
+                                              const double *__restrict__ img_all, int tiles_m, int tiles_n)
 {
-    extern __shared__ __attribute__((aligned(16))) double fsm[];
+    double *fsm = lu4_lds;
     double *img = fsm;                 // [LU_IMG + 64]
     double *xs = fsm + LU_IMG;
     double *Rl = fsm + LU_STRIDE;      // [16 NT t'][FL_LDR]: R0[s][t'] at Rl[t' * FL_LDR + s]
-    const int bid = blockIdx.x, xcd = bid & 7, seq = bid >> 3;
+    const int xcd = bid & 7, seq = bid >> 3;
     const int T = tiles_m * tiles_n;
     const int unit = (seq / T) * 8 + xcd;
     if (unit >= n_units) return;
@@ -769,6 +898,45 @@ __global__ __launch_bounds__(256) void sweep_flush_lu_kernel(int n, int n_units,
         }
 }
 
+template <bool FULL, int NT>
+__global__ __launch_bounds__(256) void sweep_flush_lu_kernel(int n, int n_units, const double *__restrict__ Gin_all,
+                                                            double *__restrict__ Gout_all, long strideG, int site0,
+                                                            int nsites, const double *__restrict__ img_all,
+                                                            int tiles_m, int tiles_n)
+{
+    flush_lu_body<FULL, NT>(blockIdx.x, n, n_units, Gin_all, Gout_all, strideG, site0, nsites, img_all, tiles_m, tiles_n);
+}
+
+// One launch per chunk boundary: the first n_walkers workgroups eliminate chunk `site0` (adding the not yet applied
+// previous chunk to their 64 x 64 block themselves), all other workgroups apply the previous chunk to G out of place.
+struct SweepFusedArgs {
+    int n, n_walkers, n_units;
+    const double *Gin;
+    double *Gout;
+    long strideG;
+    int8_t *conf_slice;
+    long conf_stride;
+    int site0, site0p;
+    double *img;         // written by the elimination of this chunk
+    const double *imgp;  // images of the previous chunk
+    SweepConsts sc;
+    WalkerRng *rngs;
+    DevStats *stats;
+    int check_sign;
+    int *errflag;
+    int tiles_m, tiles_n;
+};
+template <int NB, int NT>
+__global__ __launch_bounds__(256) void sweep_fused_kernel(SweepFusedArgs a)
+{
+    if ((int)blockIdx.x < a.n_walkers)
+        lu4_block<NB, true, true>(blockIdx.x, a.n, a.Gin, a.strideG, a.conf_slice, a.conf_stride, a.site0, 64, a.img, a.sc,
+                                  a.rngs, a.stats, a.check_sign, a.errflag, a.site0p, a.imgp);
+    else
+        flush_lu_body<true, NT>((int)blockIdx.x - a.n_walkers, a.n, a.n_units, a.Gin, a.Gout, a.strideG, a.site0p, 64,
+                                a.imgp, a.tiles_m, a.tiles_n);
+}
+
 hipError_t launch_sweep_flush_lu(int n, int n_units, const double *Gin, double *Gout, long strideG, int site0,
                                  int nsites, const double *img, hipStream_t s, hipEvent_t start, hipEvent_t stop)
 {
@@ -797,5 +965,50 @@ hipError_t launch_sweep_flush_lu(int n, int n_units, const double *Gin, double *
 #undef FL_LAUNCH
     return hipGetLastError();
 }
+
+hipError_t launch_sweep_fused(int n, int nb, int n_walkers, const double *Gin, double *Gout, long strideG,
+                              int8_t *conf_slice, long conf_stride, int site0, int site0p, double *img,
+                              const double *imgp, SweepConsts sc, WalkerRng *rng, DevStats *stats, int check_sign,
+                              int *errflag, hipStream_t s, hipEvent_t start, hipEvent_t stop)
+{
+    if (n % 64 != 0 || site0 % 64 != 0 || site0p % 64 != 0 || site0 + 64 > n || site0p + 64 > n || nb < 1 || nb > 2)
+        return hipErrorInvalidValue;
+    const int n_units = n_walkers * nb;
+    const bool wide = n % 128 == 0;
+    const int nt = wide ? 8 : 4;
+    SweepFusedArgs a;
+    a.n = n; a.n_walkers = n_walkers; a.n_units = n_units; a.Gin = Gin; a.Gout = Gout; a.strideG = strideG;
+    a.conf_slice = conf_slice; a.conf_stride = conf_stride; a.site0 = site0; a.site0p = site0p; a.img = img; a.imgp = imgp;
+    a.sc = sc; a.rngs = rng; a.stats = stats; a.check_sign = check_sign; a.errflag = errflag;
+    a.tiles_m = n / 64; a.tiles_n = n / (16 * nt);
+    const int groups = (n_units + 7) / 8;
+    const int flush_blocks = groups * 8 * a.tiles_m * a.tiles_n;
+    const size_t lds_flush = ((size_t)LU_STRIDE + 16 * nt * FL_LDR) * sizeof(double);
+    const size_t lds_lu = nb == 1 ? sizeof(Lu4Smem<1>) : sizeof(Lu4Smem<2>);
+    const size_t lds = lds_flush > lds_lu ? lds_flush : lds_lu;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    static unsigned attr_mask = 0;
+    if (!(attr_mask & (1u << dev))) {
+        (void)hipFuncSetAttribute((const void *)sweep_fused_kernel<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)sweep_fused_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)sweep_fused_kernel<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)sweep_fused_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_mask |= 1u << dev;
+    }
+    dim3 grid(n_walkers + flush_blocks), block(256);
+#define FU_LAUNCH(NBV, NTV) hipExtLaunchKernelGGL((sweep_fused_kernel<NBV, NTV>), grid, block, lds, s, start, stop, 0, a)
+    if (nb == 1) { if (wide) FU_LAUNCH(1, 8); else FU_LAUNCH(1, 4); }
+    else { if (wide) FU_LAUNCH(2, 8); else FU_LAUNCH(2, 4); }
+#undef FU_LAUNCH
+    return hipGetLastError();
+}
+
+#ifdef LU4_STAMPS
+extern "C" int dqmc_debug_lu4_stamps(void *devptr)
+{
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(lu4_stamp_ptr), &devptr, sizeof(void *));
+}
+#endif
 
 }  // namespace dqmc

@@ -47,12 +47,32 @@ def main():
         return [float(x) for x in t.replace("\n", " ").split(",")]
     cdc_att = vec(att, r"# Charge Density Correlation\s*@test \[(.*?)\]\[:\] ≈ mean\(measured\[:CDC\]\)")
     sdcx_att = vec(att, r"# Spin density correlations \(x, y, z\)\s*@test \[(.*?)\]\[:\] ≈ mean\(measured\[:SDCx\]\)")
-    json.dump({"source": "test/integration_tests.jl:29-75 (attractive 4x4, beta=1, 10+1000 sweeps, "
-                         "measure_rate 10; atol = 4*dtau^2 = 0.04)", "L": 4, "beta": 1.0, "atol": 0.04,
-               "G_mean_colmajor": g_att, "CDC_mean": cdc_att, "SDCx_mean": sdcx_att},
+
+    def all_goldens(block):
+        """every `@test [numbers] ≈ <observable>` of a testset: {observable: {mean, std_error, has_atol}} (numbers
+        only; `conf` is the mean of the recorded configurations, Julia matrix literal = rows separated by ';')"""
+        out = {}
+        for mm in re.finditer(r"@test \[(.*?)\]\s*(?:\[:\])?\s*≈\s*([^\n]*)", block, re.S):
+            body, rhs = re.sub(r"\+ 0\.0im", "", mm.group(1)), mm.group(2)
+            rows = [[float(x) for x in re.split(r"[,\s]+", r.strip()) if x] for r in body.replace("\n", " ").split(";")]
+            key = re.search(r"measured\[:(\w+)\]", rhs)
+            name = key.group(1) if key else "conf"
+            ent = out.setdefault(name, {})
+            ent["std_error" if "std_error" in rhs else "mean"] = rows if len(rows) > 1 else rows[0]
+            ent["has_atol"] = "atol" in rhs
+        return out
+
+    json.dump({"source": "test/integration_tests.jl:29-94 (attractive 4x4, beta=1, 10+1000 sweeps, "
+                         "measure_rate 10 = 100 measurements; atol = 4*dtau^2 = 0.04); `all` = every golden of the "
+                         "testset (mean and std_error of G, CDC, SDCx/y/z, PC with K=5; mean of the recorded HS "
+                         "fields), numbers only", "L": 4, "beta": 1.0, "atol": 0.04, "n_measurements": 100,
+               "G_mean_colmajor": g_att, "CDC_mean": cdc_att, "SDCx_mean": sdcx_att, "all": all_goldens(att)},
               open(os.path.join(OUT, "integration_attractive_4x4.json"), "w"))
-    json.dump({"source": "test/integration_tests.jl:95-118 (repulsive 2x2, beta=1, 10+1000 sweeps; "
-                         "atol = 2*dtau^2 = 0.02)", "L": 2, "beta": 1.0, "atol": 0.02, "G_mean": g_rep},
+    json.dump({"source": "test/integration_tests.jl:98-185 (repulsive 2x2, beta=1, 10+1000 sweeps = 100 measurements; "
+                         "atol = 2*dtau^2 = 0.02 where the reference gives one - CDC, Mz, SDC and PC are compared "
+                         "with Julia's default isapprox there, i.e. bit-for-bit regression values of its own RNG "
+                         "stream); `all` = every golden of the testset", "L": 2, "beta": 1.0, "atol": 0.02,
+               "n_measurements": 100, "G_mean": g_rep, "all": all_goldens(rep[:rep.index("# TODO")])},
               open(os.path.join(OUT, "integration_repulsive_2x2.json"), "w"))
 
     # ---- (b) vectors from the independent restatements
