@@ -267,6 +267,11 @@ int dqmc_calculate_greens(int32_t device_id, int32_t n, int32_t batch, const dou
                           const double *Dl, const double *Tl, const double *Ur, const double *Dr,
                           const double *Tr, double *G);
 
+/* The cooperative QR (8 workgroups per matrix, bounded hand-off spins) leaves its input intact; if a launch times
+ * out (CUs held by another stream for longer than the spins allow), the guarded single-workgroup kernel launched
+ * behind it redoes the factorisation, so results stay valid.  This counter reports how often that happened. */
+int dqmc_qr_fallbacks(dqmc_handle *h, int64_t *count);
+
 /* ---- instrumentation ------------------------------------------------------ */
 /* Per-kernel-family device time accumulated with HIP events on the handle's
  * stream when enabled (off by default; used by bench.py's roofline leg). */

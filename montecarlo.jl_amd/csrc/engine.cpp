@@ -274,8 +274,9 @@ static int alloc_qr_workspace(dqmc_handle *h)
     HIPCHK(hipGetDeviceProperties(&prop, h->p.device_id));
     const size_t slots = (size_t)((h->units + 7) / 8) * 8 * 2 * 8;  // units x parity x 8 parts
     CHK(dalloc(h, &h->qr_ws.mailbox, slots * QR_COOP_SLOT));
-    // co-residency: the kernel's 200 VGPRs admit 2 workgroups of 256 threads per CU
-    h->qr_ws.max_blocks = prop.multiProcessorCount * 2;
+    CHK(dalloc(h, &h->qr_ws.fb, (size_t)2));
+    // co-residency: what the occupancy API reports for the kernel on this device (its ~200 VGPRs admit 2 per CU)
+    h->qr_ws.max_blocks = prop.multiProcessorCount * qr_coop_blocks_per_cu();
     h->qr_ws.epoch = 0;
     return 0;
 }
@@ -299,13 +300,14 @@ static int check_qr_workspace(dqmc_handle *h)
 static int udt(dqmc_handle *h, double *A, double *Uout, double *Dout, double *Tout, int apply)
 {
     const int n = h->n;
+    const double *F = A;  // where the factored matrix ends up (qrW behind the cooperative QR)
     {
         Timed t(h, DQMC_K_QR);
-        HIPCHK(launch_qr_pivot(n, h->units, A, h->nn, h->tau, h->pivot, &h->qr_ws, h->stream));
+        HIPCHK(launch_qr_pivot(n, h->units, A, h->nn, h->tau, h->pivot, &h->qr_ws, h->qrW, h->nn, &F, h->stream));
     }
     {
         Timed t(h, DQMC_K_MISC);
-        HIPCHK(launch_udt_finish(n, h->units, A, h->nn, h->pivot, Dout, n, h->qrV, h->nn, Tout, h->nn, apply,
+        HIPCHK(launch_udt_finish(n, h->units, A, h->nn, F, h->nn, h->pivot, Dout, n, h->qrV, h->nn, Tout, h->nn, apply,
                                  h->stream));
     }
     GemmArgs g = gemm_base(h, U_(h, h->qrV), 1, U_(h, h->qrV), 0, h->qrS);
@@ -1378,6 +1380,20 @@ int dqmc_get_reduced_stats(dqmc_handle *h, dqmc_stats *out)
     if (!h || !out) return DQMC_ERR_INVALID;
     if (!h->red_valid) return fail(h, DQMC_ERR_STATE, "call dqmc_reduce first");
     *out = h->red_stats;
+    return DQMC_OK;
+}
+
+// diagnostics: cooperative-QR launches whose hand-offs timed out and were redone by the single-workgroup kernel
+int dqmc_qr_fallbacks(dqmc_handle *h, int64_t *count)
+{
+    ENTER(h);
+    if (!count) return DQMC_ERR_INVALID;
+    *count = 0;
+    if (!h->qr_ws.fb) return DQMC_OK;
+    int fb[2] = {0, 0};
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(fb, h->qr_ws.fb, sizeof(fb), hipMemcpyDeviceToHost));
+    *count = fb[1];
     return DQMC_OK;
 }
 

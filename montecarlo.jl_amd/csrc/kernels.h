@@ -81,20 +81,26 @@ constexpr int QR_COOP_SLOT = 528;  // 264 packets of 16 bytes
 struct QrCoopWorkspace {
     double *mailbox = nullptr;
     int *errflag = nullptr;
+    int *fb = nullptr;    // [0] launch epoch of the last cooperative launch that timed out, [1] fallbacks taken
     unsigned long long epoch = 0;
     int max_blocks = 0;   // launch the cooperative kernel only if its grid fits (co-residency)
 };
 // ws may be null: single-workgroup kernels only
+// W (n_units x strideW, may be null): output of the cooperative kernel, which leaves A intact so that a time-out of
+// its hand-offs can be recovered by the single-workgroup kernel launched (guarded) behind it; *factored tells where
+// the factored matrix is (W or A)
 hipError_t launch_qr_pivot(int n, int n_units, double *A, long strideA, double *tau, int *pivot,
-                           QrCoopWorkspace *ws, hipStream_t s);
+                           QrCoopWorkspace *ws, double *W, long strideW, const double **factored, hipStream_t s);
+int qr_coop_blocks_per_cu();
 
 // After launch_qr_pivot: D = |diag R| (UDT.jl:268-272); V = unit-lower Householder
 // vectors (n x n, explicit zeros/ones); T = D^-1 R:
 //   apply_pivot = 1: Tout[i, pivot[j]] = R[i,j]/D[i], zero elsewhere (UDT.jl:283-297), out of place
 //   apply_pivot = 0: A[i,j] *= 1/D[i] for j >= i in place, below-diagonal left dirty (UDT.jl:298-306)
-hipError_t launch_udt_finish(int n, int n_units, double *A, long strideA, const int *pivot, double *D,
-                             long strideD, double *V, long strideV, double *Tout, long strideT,
-                             int apply_pivot, hipStream_t s);
+// F = the factored matrix (A itself for the in-place kernels)
+hipError_t launch_udt_finish(int n, int n_units, double *A, long strideA, const double *F, long strideF,
+                             const int *pivot, double *D, long strideD, double *V, long strideV, double *Tout,
+                             long strideT, int apply_pivot, hipStream_t s);
 
 // X = gather(A)[:, pivot] * triu(T)^-1 written to Out (rdivp!, src/linalg/general.jl:138-166).
 // pivot may be null (identity).  If dmul != null the diagonal of T is ignored and

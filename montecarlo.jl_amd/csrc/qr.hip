@@ -28,9 +28,20 @@ constexpr int QR_WAVES = QR_THREADS / 64;
 template <int QMAX, int QR_UC>
 __global__ __launch_bounds__(QR_THREADS) void qr_pivot_kernel(int n, double *__restrict__ Aall, long strideA,
                                                              double *__restrict__ tauall,
-                                                             int *__restrict__ pivall)
+                                                             int *__restrict__ pivall,
+                                                             const double *__restrict__ srcall, long strideSrc,
+                                                             int *guard, int guard_val)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
+    // fallback use: runs only if the cooperative kernel of this launch epoch timed out, on a fresh copy of the input
+    if (guard && guard[0] != guard_val) return;
+    if (srcall) {
+        const double *__restrict__ src = srcall + (long)blockIdx.x * strideSrc;
+        double *__restrict__ dst = Aall + (long)blockIdx.x * strideA;
+        for (long i = threadIdx.x; i < (long)n * n; i += QR_THREADS) dst[i] = src[i];
+        if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&guard[1], 1);
+        __syncthreads();
+    }
     double *v = sm;             // current reflector, v[j] = 1, v[r<j] = 0
     double *norms = sm + 1024;  // squared norms of trailing columns over rows >= j
     __shared__ int s_jm;
@@ -415,9 +426,19 @@ __device__ __forceinline__ void qt_step(int n, int j, double *__restrict__ A, do
 
 __global__ __launch_bounds__(QT_THREADS) void qr_tile256_kernel(int n, int nsteps, double *__restrict__ Aall, long strideA,
                                                                double *__restrict__ tauall,
-                                                               int *__restrict__ pivall)
+                                                               int *__restrict__ pivall,
+                                                               const double *__restrict__ srcall, long strideSrc,
+                                                               int *guard, int guard_val)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
+    if (guard && guard[0] != guard_val) return;  // fallback use, see qr_pivot_kernel
+    if (srcall) {
+        const double *__restrict__ src = srcall + (long)blockIdx.x * strideSrc;
+        double *__restrict__ dst = Aall + (long)blockIdx.x * strideA;
+        for (long i = threadIdx.x; i < (long)n * n; i += QT_THREADS) dst[i] = src[i];
+        if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&guard[1], 1);
+        __syncthreads();
+    }
     __shared__ double cand_v[8];
     __shared__ int cand_i[8];
     double *Lc = sm;                        // [64][QT_LSTRIDE] positions 64..127
@@ -489,7 +510,7 @@ __global__ __launch_bounds__(QT_THREADS) void qr_tile256_kernel(int n, int nstep
 // Every spin is bounded; a timeout raises a flag that the host reports.
 constexpr int QC_PARTS = 8;
 constexpr int QC_MB = 264;          // packets (16 B) per mailbox slot: 256 column entries + header
-constexpr unsigned QC_SPIN_LIMIT = 4000000u;
+constexpr unsigned QC_SPIN_LIMIT = 400000u;  // about 0.2 s of polling: far beyond any legitimate co-residency delay
 
 typedef unsigned long long qc_word;
 __device__ __forceinline__ void qc_put(qc_word *slot, double v, unsigned tag_lo, unsigned tag_hi)
@@ -604,7 +625,8 @@ __device__ __forceinline__ double qc_apply(double (&x)[32], const double *vq, do
 __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double *__restrict__ Aall, long strideA,
                                                      double *__restrict__ tauall, int *__restrict__ pivall,
                                                      double *mailbox,
-                                                     unsigned long long epoch, int *errflag, int force_sc1)
+                                                     unsigned long long epoch, int *fb, int force_sc1,
+                                                     double *__restrict__ Wall, long strideW, int force_timeout)
 {
     // my best column, permuted by row group like vperm: row r at (r & 7) * QT_VS + (r >> 3), so that an owner
     // lane (rows rg + 8k) stores pairs of consecutive k with 16-byte writes
@@ -619,7 +641,14 @@ __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double
     const int bid = blockIdx.x, xcd = bid & 7, seq = bid >> 3;
     const int unit = (seq / QC_PARTS) * 8 + xcd, part = seq % QC_PARTS;
     if (unit >= n_units) return;  // all parts of a missing unit leave together
-    double *__restrict__ A = Aall + (long)unit * strideA;
+    // The factored matrix goes to W, the input A is only read: a hand-off time-out therefore leaves the input intact
+    // and the guarded single-workgroup kernel launched behind this one redoes the factorisation (fb[0] = epoch).
+    if (force_timeout) {  // test hook (DQMC_QR_FORCE_TIMEOUT): behave like a launch whose hand-offs timed out
+        if (threadIdx.x == 0) atomicExch(&fb[0], (int)(epoch & 0x7fffffffull));
+        return;
+    }
+    const double *__restrict__ A = Aall + (long)unit * strideA;
+    double *__restrict__ Wo = Wall + (long)unit * strideW;
     double *__restrict__ tau = tauall + (long)unit * n;
     int *__restrict__ piv = pivall + (long)unit * n;
     qc_word *mb_unit = reinterpret_cast<qc_word *>(mailbox) + (long)unit * 2 * QC_PARTS * QC_MB * 2;
@@ -797,7 +826,7 @@ __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double
             double vr = (r == j) ? 1.0 : ((nz && r > j) ? scaled : 0.0);
             if (r >= n) vr = 0.0;
             vperm[(r & 7) * QT_VS + (r >> 3)] = vr;
-            if (part == wpart && r < n) A[r + (long)n * j] = outv;  // the owner writes the finished column
+            if (part == wpart && r < n) Wo[r + (long)n * j] = outv;  // the owner writes the finished column
         }
         // swap positions j <-> jm (UDT.jl:219-231): every thread tracks its own column, thread 0 the table
         {
@@ -828,47 +857,44 @@ __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double
         // (pos/colat are rewritten by thread 0 only after the barriers of the next step)
     }
     if (s_abort) {
-        if (tid == 0) atomicOr(errflag, 1);
+        if (tid == 0) atomicExch(&fb[0], (int)(epoch & 0x7fffffffull));
         return;
     }
     __syncthreads();
     if (part == 0 && tid < n) piv[tid] = colat[tid];
 }
 
-hipError_t launch_qr_pivot(int n, int n_units, double *A, long strideA, double *tau, int *pivot, QrCoopWorkspace *ws,
-                           hipStream_t s)
+// blocks of qr_coop_kernel that one CU holds at a time (occupancy API, capped at the 2 that its registers admit)
+int qr_coop_blocks_per_cu()
 {
-    if (n > 1024) return hipErrorInvalidValue;
-    static const bool no_coop = getenv("DQMC_QR_NOCOOP") != nullptr;
-    // cooperative kernel: all 8 workgroups of every unit must be co-resident (they wait for each
-    // other), which the grid size guarantees only while it stays well below the chip's capacity
-    if (ws && ws->mailbox && n <= 256 && !no_coop) {
-        const int groups = (n_units + 7) / 8;
-        const int blocks = groups * 8 * QC_PARTS;
-        if (blocks <= ws->max_blocks) {
-            ws->epoch += 1;
-            static const int force_sc1 = getenv("DQMC_QR_SC1") != nullptr;  // write-through packets regardless of placement
-            hipLaunchKernelGGL(qr_coop_kernel, dim3(blocks), dim3(256), 0, s, n, n_units, A, strideA, tau, pivot,
-                               ws->mailbox, ws->epoch, ws->errflag, force_sc1);
-            return hipGetLastError();
-        }
-    }
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, qr_coop_kernel, 256, 0) != hipSuccess) return 1;
+    return nb < 1 ? 1 : (nb > 2 ? 2 : nb);
+}
+
+static hipError_t launch_qr_single(int n, int n_units, double *A, long strideA, double *tau, int *pivot,
+                                   const double *src, long strideSrc, int *guard, int guard_val, hipStream_t s)
+{
     static const bool no_tile = getenv("DQMC_QR_STREAM") != nullptr;
     if (n > 128 && n <= 256 && !no_tile) {
         const size_t lds_t = (64 * QT_LSTRIDE + 3 * 256 + 8 * QT_VS + 8 * 256) * sizeof(double) + 256 * sizeof(int);
-        static bool attr_set = false;
-        if (!attr_set) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        static unsigned attr_mask = 0;  // per device
+        if (!(attr_mask & (1u << dev))) {
             (void)hipFuncSetAttribute((const void *)qr_tile256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds_t);
-            attr_set = true;
+            attr_mask |= 1u << dev;
         }
         const int nsteps = n;
-        hipLaunchKernelGGL(qr_tile256_kernel, dim3(n_units), dim3(QT_THREADS), lds_t, s, n, nsteps, A, strideA, tau, pivot);
+        hipLaunchKernelGGL(qr_tile256_kernel, dim3(n_units), dim3(QT_THREADS), lds_t, s, n, nsteps, A, strideA, tau, pivot,
+                           src, strideSrc, guard, guard_val);
         return hipGetLastError();
     }
     const size_t lds = 2 * 1024 * sizeof(double);
     dim3 grid(n_units), block(QR_THREADS);
-#define QR_LAUNCH(Q, UC) hipLaunchKernelGGL((qr_pivot_kernel<Q, UC>), grid, block, lds, s, n, A, strideA, tau, pivot)
+#define QR_LAUNCH(Q, UC) \
+    hipLaunchKernelGGL((qr_pivot_kernel<Q, UC>), grid, block, lds, s, n, A, strideA, tau, pivot, src, strideSrc, guard, guard_val)
     if (n <= 64) QR_LAUNCH(1, 4);
     else if (n <= 128) QR_LAUNCH(2, 4);
     else if (n <= 256) QR_LAUNCH(4, 4);
@@ -878,9 +904,39 @@ hipError_t launch_qr_pivot(int n, int n_units, double *A, long strideA, double *
     return hipGetLastError();
 }
 
+// *factored: where the factored matrix is (W for the cooperative kernel, which leaves A untouched; else A, in place)
+hipError_t launch_qr_pivot(int n, int n_units, double *A, long strideA, double *tau, int *pivot, QrCoopWorkspace *ws,
+                           double *W, long strideW, const double **factored, hipStream_t s)
+{
+    if (n > 1024) return hipErrorInvalidValue;
+    *factored = A;
+    static const bool no_coop = getenv("DQMC_QR_NOCOOP") != nullptr;
+    // cooperative kernel: all 8 workgroups of every unit must be co-resident (they wait for each other); the grid is
+    // admitted only if it fits the occupancy the runtime reports for this kernel.  Should another stream hold CUs
+    // for longer than the bounded spins allow, the launch gives up and the guarded kernel behind it takes over.
+    if (ws && ws->mailbox && W && n <= 256 && !no_coop) {
+        const int groups = (n_units + 7) / 8;
+        const int blocks = groups * 8 * QC_PARTS;
+        if (blocks <= ws->max_blocks) {
+            ws->epoch += 1;
+            static const int force_sc1 = getenv("DQMC_QR_SC1") != nullptr;  // write-through packets regardless of placement
+            static const int force_to = getenv("DQMC_QR_FORCE_TIMEOUT") != nullptr;
+            hipLaunchKernelGGL(qr_coop_kernel, dim3(blocks), dim3(256), 0, s, n, n_units, A, strideA, tau, pivot,
+                               ws->mailbox, ws->epoch, ws->fb, force_sc1, W, strideW, force_to);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return e;
+            *factored = W;
+            return launch_qr_single(n, n_units, W, strideW, tau, pivot, A, strideA, ws->fb,
+                                    (int)(ws->epoch & 0x7fffffffull), s);
+        }
+    }
+    return launch_qr_single(n, n_units, A, strideA, tau, pivot, nullptr, 0, nullptr, 0, s);
+}
+
 // D, V and T from the factored matrix (UDT.jl:268-306).  One workgroup per unit.
 constexpr int UF_SPLIT = 8;  // workgroups per matrix (column slabs): 32 matrices alone would leave 7/8 of the chip idle
 __global__ __launch_bounds__(256) void udt_finish_kernel(int n, double *__restrict__ Aall, long strideA,
+                                                        const double *__restrict__ Fall, long strideF,
                                                         const int *__restrict__ pivall,
                                                         double *__restrict__ Dall, long strideD,
                                                         double *__restrict__ Vall, long strideV,
@@ -889,12 +945,13 @@ __global__ __launch_bounds__(256) void udt_finish_kernel(int n, double *__restri
     extern __shared__ __attribute__((aligned(16))) double dinv[];  // 1/D
     const int unit = blockIdx.x / UF_SPLIT, slab = blockIdx.x % UF_SPLIT;
     double *__restrict__ A = Aall + (long)unit * strideA;
+    const double *__restrict__ F = Fall + (long)unit * strideF;  // the factored matrix (may be A itself)
     double *__restrict__ D = Dall + (long)unit * strideD;
     const int *__restrict__ piv = pivall + (long)unit * n;
     double *__restrict__ V = Vall ? Vall + (long)unit * strideV : nullptr;
     double *__restrict__ T = Tall ? Tall + (long)unit * strideT : nullptr;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const double d = fabs(A[i + (long)n * i]);
+        const double d = fabs(F[i + (long)n * i]);
         if (slab == 0) D[i] = d;
         dinv[i] = 1.0 / d;
     }
@@ -906,7 +963,7 @@ __global__ __launch_bounds__(256) void udt_finish_kernel(int n, double *__restri
         for (int q = 0; q < rpt; ++q) {
             const int r = lane + 64 * q;
             if (r >= n) break;
-            const double a = A[r + (long)n * c];
+            const double a = F[r + (long)n * c];
             if (V) V[r + (long)n * c] = r > c ? a : (r == c ? 1.0 : 0.0);
             if (apply_pivot) T[r + (long)n * pc] = r <= c ? dinv[r] * a : 0.0;
             else if (r <= c) A[r + (long)n * c] = dinv[r] * a;
@@ -914,12 +971,12 @@ __global__ __launch_bounds__(256) void udt_finish_kernel(int n, double *__restri
     }
 }
 
-hipError_t launch_udt_finish(int n, int n_units, double *A, long strideA, const int *pivot, double *D,
-                             long strideD, double *V, long strideV, double *Tout, long strideT,
-                             int apply_pivot, hipStream_t s)
+hipError_t launch_udt_finish(int n, int n_units, double *A, long strideA, const double *F, long strideF,
+                             const int *pivot, double *D, long strideD, double *V, long strideV, double *Tout,
+                             long strideT, int apply_pivot, hipStream_t s)
 {
     hipLaunchKernelGGL(udt_finish_kernel, dim3(n_units * UF_SPLIT), dim3(256), n * sizeof(double), s, n, A, strideA,
-                       pivot, D, strideD, V, strideV, Tout, strideT, apply_pivot);
+                       F, strideF, pivot, D, strideD, V, strideV, Tout, strideT, apply_pivot);
     return hipGetLastError();
 }
 

@@ -568,6 +568,12 @@ class DQMC:
         return res
 
     # ---- instrumentation
+    def qr_fallbacks(self):
+        """cooperative-QR launches that timed out and were redone by the single-workgroup kernel"""
+        n = C.c_int64()
+        self._c(lib().dqmc_qr_fallbacks(self._h, C.byref(n)))
+        return n.value
+
     def timing_enable(self, on=True):
         self._c(lib().dqmc_timing_enable(self._h, int(on)))
 

@@ -1,5 +1,7 @@
 """GPU parity of the DQMC sweep path against the CPU oracle on identical seeds:
 HS field bit-exact, effective Green's function within 1e-10 relative."""
+import os
+
 import numpy as np
 import pytest
 
@@ -7,6 +9,7 @@ from conftest import relerr
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-10
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def make_pair(gpu, O, L, kind, beta, n_walkers=2, seed=123, **kw):
@@ -201,3 +204,34 @@ def test_odd_sizes_padding_paths(gpu, O, kind, L):
             o.update()
     compare(mc, refs)
     mc.close()
+
+
+def test_cooperative_qr_timeout_falls_back(gpu, O):
+    """A cooperative-QR launch whose hand-offs time out must not corrupt anything: the kernel leaves its input intact
+    and the guarded single-workgroup kernel behind it redoes the factorisation.  DQMC_QR_FORCE_TIMEOUT makes every
+    cooperative launch give up at once (read at the first launch, hence a child process)."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, %r)
+        import __graft_entry__ as g
+        gpu = g.load_package(); O = g.load_oracle()
+        mc = gpu.DQMC(gpu.HubbardModelAttractive(4, 2), beta=1.0, n_walkers=2, seed=11)
+        ref = []
+        for w in range(2):
+            o = O.OracleDQMC(4, "attractive", beta=1.0); o.set_conf(mc.conf(w)); o.seed(mc.seeds[w]); o.prepare(); ref.append(o)
+        mc.prepare()
+        for _ in range(25):
+            mc.update(); [o.update() for o in ref]
+        for w, o in enumerate(ref):
+            assert np.array_equal(mc.conf(w), o.conf())
+            e = np.abs(mc.greens_eff(w)[0] - o.greens_eff()[0]).max() / np.abs(o.greens_eff()[0]).max()
+            assert e < 1e-10, e
+        n = mc.qr_fallbacks()
+        assert n > 0, "the forced time-outs were not taken"
+        print("fallbacks", n)
+    """ % ROOT)
+    env = dict(os.environ, DQMC_QR_FORCE_TIMEOUT="1")
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "fallbacks" in p.stdout
