@@ -267,6 +267,20 @@ int dqmc_calculate_greens(int32_t device_id, int32_t n, int32_t batch, const dou
                           const double *Dl, const double *Tl, const double *Ur, const double *Dr,
                           const double *Tr, double *G);
 
+/* CheckerboardTrue (DQMC(m; checkerboard=true), DQMC.jl:250-263) with the bond-group factors kept SPARSE on the
+ * device: chkr_hop_half[g], chkr_hop[1], their inverses (and the adjoints, as separate factors) of
+ * init_checkerboard_matrices (stack.jl:185-235) in ELL form - vals / cols [n_mats][n_sites][kmax], 0-based columns,
+ * padding entries val = 0 - plus chkr_mu / chkr_mu_inv per block [n_blocks][n_sites] and seven factor sequences
+ * (each up to 32 indices into the factor list, applied first to last):
+ *   0 B X   (multiply_slice_matrix_left!, slice_matrices.jl:104-124)     3 X B    (:125-149)
+ *   1 B^-1 X (:150-171)                                                   4 X B^-1 (:172-196)
+ *   2 B' X  (multiply_daggered_slice_matrix_left!, :197-222)              5 X eT, 6 eTinv X (greens(), DQMC.jl:731-750)
+ * Right products take the factors' transposes (rows of H' = columns of H).  After this call the propagation path
+ * applies these sequences slab by slab in LDS instead of dense GEMMs with the multiplied-out constants (which
+ * dqmc_create still needs: the unequal-time path uses them). */
+int dqmc_set_checkerboard(dqmc_handle *h, int32_t kmax, int32_t n_mats, const double *vals, const int32_t *cols,
+                          const double *mu, const double *mu_inv, const int32_t *seqs, const int32_t *lens);
+
 /* The cooperative QR (8 workgroups per matrix, bounded hand-off spins) leaves its input intact; if a launch times
  * out (CUs held by another stream for longer than the spins allow), the guarded single-workgroup kernel launched
  * behind it redoes the factorisation, so results stay valid.  This counter reports how often that happened. */

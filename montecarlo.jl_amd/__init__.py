@@ -15,6 +15,6 @@ from .models import (HubbardModel, HubbardModelAttractive, HubbardModelRepulsive
 from .sharding import (Communicator, reduce_accumulators, walker_block, walker_range,  # noqa: F401
                        walker_seeds)
 from .dqmc import (DQMC, DQMCParameters, calculate_greens_AVX, device_count,  # noqa: F401
-                   checkerboard_exponentials, hopping_exponentials, mfma_f64_peak, rdivp, udt_AVX_pivot, vmul)
+                   checkerboard_exponentials, checkerboard_tables, hopping_exponentials, mfma_f64_peak, rdivp, udt_AVX_pivot, vmul)
 
 lib()  # fail loudly at import time if the HIP library has not been built

@@ -114,6 +114,8 @@ SIGNATURES = {
     "dqmc_udt_pivot": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _dp, _dp, _dp, _i64p, C.c_int32]),
     "dqmc_rdivp": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _dp, _dp, _i64p]),
     "dqmc_calculate_greens": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
+    "dqmc_set_checkerboard": (C.c_int, [_H, C.c_int32, C.c_int32, _dp, C.POINTER(C.c_int32), _dp, _dp,
+                              C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "dqmc_qr_fallbacks": (C.c_int, [_H, C.POINTER(C.c_int64)]),
     "dqmc_timing_enable": (C.c_int, [_H, C.c_int32]),
     "dqmc_timing_get": (C.c_int, [_H, _dp, _i64p]),

@@ -78,6 +78,15 @@ struct dqmc_handle {
     long long fam_n[DQMC_K_COUNT] = {0};
     std::vector<void *> allocs;
     QrCoopWorkspace qr_ws;
+    // checkerboard products with sparse bond-group factors (cb.hip); the dense constants above stay valid
+    struct {
+        bool on = false;
+        int kmax = 0, n_mats = 0;
+        double *vals = nullptr, *mu = nullptr, *mu_inv = nullptr;
+        int *cols = nullptr;
+        int seq[7][32];
+        int len[7] = {0, 0, 0, 0, 0, 0, 0};
+    } cb;
     // measurement reduction (dqmc_reduce): packed device buffer [sums | maxima | minima]
     double *red_buf = nullptr;
     size_t red_cap = 0;
@@ -354,6 +363,37 @@ static int calculate_greens(dqmc_handle *h, double *out)
     return 0;
 }
 
+
+// ---- checkerboard products with sparse factors (slice_matrices.jl:104-222, DQMC.jl:731-750) --------------------
+enum { CB_LEFT_B = 0, CB_LEFT_BINV = 1, CB_LEFT_BDAG = 2, CB_RIGHT_B = 3, CB_RIGHT_BINV = 4, CB_RIGHT_ET = 5,
+       CB_LEFT_ETINV = 6 };
+static int cb_mult(dqmc_handle *h, int which, int slice, const double *X, double *O, const double *qscale)
+{
+    CbArgs a{};
+    a.n = h->n; a.nb = h->nb; a.kmax = h->cb.kmax;
+    a.side = (which == CB_RIGHT_B || which == CB_RIGHT_BINV || which == CB_RIGHT_ET) ? 1 : 0;
+    a.seq_len = h->cb.len[which];
+    for (int i = 0; i < a.seq_len; ++i) a.seq[i] = h->cb.seq[which][i];
+    a.vals = h->cb.vals; a.cols = h->cb.cols;
+    a.X = X; a.O = O; a.strideX = h->nn;
+    a.conf = slice >= 1 ? h->conf + (long)(slice - 1) * h->N : nullptr;
+    a.conf_stride = (long)h->N * h->M;
+    a.epl = h->epl; a.eml = h->eml;
+    switch (which) {
+    case CB_LEFT_B: a.pre_conf = +1; a.pre_vec = h->cb.mu; break;
+    case CB_LEFT_BINV: a.post_conf = -1; a.post_vec = h->cb.mu_inv; break;
+    case CB_LEFT_BDAG: a.post_conf = +1; a.post_vec = h->cb.mu; break;
+    case CB_RIGHT_B: a.post_conf = +1; a.post_vec = h->cb.mu; break;
+    case CB_RIGHT_BINV: a.pre_conf = -1; a.pre_vec = h->cb.mu_inv; break;
+    default: break;
+    }
+    a.qscale = qscale; a.qstride = h->n;
+    hipEvent_t ea, eb;
+    timing_events(h, &ea, &eb);
+    HIPCHK(launch_cb_apply(a, h->units, h->stream, ea, eb));
+    return timing_push(h, ea, eb, DQMC_K_GEMM);
+}
+
 // ---- slice sequences (stack.jl:272-311, slice_matrices.jl:42-76) -------------------
 static int add_slice_sequence_left(dqmc_handle *h, int idx)  // idx 1-based as in the reference
 {
@@ -362,6 +402,11 @@ static int add_slice_sequence_left(dqmc_handle *h, int idx)  // idx 1-based as i
     for (int t = 0; t < h->s; ++t) {
         const int slice = (idx - 1) * h->s + 1 + t;
         out = (t & 1) ? h->bufB : h->bufA;
+        if (h->cb.on) {
+            CHK(cb_mult(h, CB_LEFT_B, slice, X, out, t == h->s - 1 ? dslot(h, idx - 1) : nullptr));
+            X = out;
+            continue;
+        }
         GemmArgs g = gemm_base(h, C_(h, h->eT2), 0, U_(h, X), 0, out);
         g.kscale = vs_conf(h, slice, +1);
         if (t == h->s - 1) g.colscale = vs_arr(dslot(h, idx - 1), h->n);  // stack.jl:281
@@ -379,6 +424,11 @@ static int add_slice_sequence_right(dqmc_handle *h, int idx)
     for (int t = 0; t < h->s; ++t) {
         const int slice = idx * h->s - t;
         out = (t & 1) ? h->bufB : h->bufA;
+        if (h->cb.on) {
+            CHK(cb_mult(h, CB_LEFT_BDAG, slice, X, out, t == h->s - 1 ? dslot(h, idx) : nullptr));
+            X = out;
+            continue;
+        }
         GemmArgs g = gemm_base(h, C_(h, h->eT2), 1, U_(h, X), 0, out);  // (eT2*eV)' = eV*eT2'
         g.rowscale = vs_conf(h, slice, +1);
         g.row_first = 1;
@@ -394,6 +444,12 @@ static int add_slice_sequence_right(dqmc_handle *h, int idx)
 // wrap_greens! (stack.jl:491-500)
 static int wrap_greens(dqmc_handle *h, double *gf, int curr_slice, int direction)
 {
+    if (h->cb.on) {  // both products in place, slab by slab
+        const int l = direction == -1 ? curr_slice - 1 : curr_slice;
+        CHK(cb_mult(h, direction == -1 ? CB_LEFT_BINV : CB_LEFT_B, l, gf, gf, nullptr));
+        CHK(cb_mult(h, direction == -1 ? CB_RIGHT_B : CB_RIGHT_BINV, l, gf, gf, nullptr));
+        return 0;
+    }
     if (direction == -1) {
         const int l = curr_slice - 1;
         GemmArgs g = gemm_base(h, C_(h, h->eTinv2), 0, U_(h, gf), 0, h->tmp1);  // (eV^-1 eTinv2) * G
@@ -917,6 +973,11 @@ int dqmc_set_greens_eff(dqmc_handle *h, int32_t w, const double *in)
 // greens!(mc): temp = greens*eT; out = eTinv*temp (DQMC.jl:721-730); result in tmp2
 static int true_greens(dqmc_handle *h, const double *src)
 {
+    if (h->cb.on) {
+        CHK(cb_mult(h, CB_RIGHT_ET, 0, src, h->tmp1, nullptr));
+        CHK(cb_mult(h, CB_LEFT_ETINV, 0, h->tmp1, h->tmp2, nullptr));
+        return 0;
+    }
     CHK(run_gemm(h, gemm_base(h, U_(h, src), 0, C_(h, h->eT), 0, h->tmp1)));
     CHK(run_gemm(h, gemm_base(h, C_(h, h->eTinv), 0, U_(h, h->tmp1), 0, h->tmp2)));
     return 0;
@@ -938,12 +999,15 @@ static int calculate_greens_from_scratch(dqmc_handle *h, int slice, double *outp
     CHK(set_identity(h, h->bufA)); CHK(set_identity(h, h->Ur)); CHK(set_ones(h, h->Dr)); CHK(set_identity(h, h->Tr));
     double *cur = h->bufA, *oth = h->bufB;
     auto chain_step = [&](int k, bool dagger, bool stab, double *D, double *T, double *Ufinal) -> int {
-        GemmArgs g = dagger ? gemm_base(h, C_(h, h->eT2), 1, U_(h, cur), 0, oth)
-                            : gemm_base(h, C_(h, h->eT2), 0, U_(h, cur), 0, oth);
-        if (dagger) { g.rowscale = vs_conf(h, k, +1); g.row_first = 1; }
-        else g.kscale = vs_conf(h, k, +1);
-        if (stab) g.colscale = vs_arr(D, n);
-        CHK(run_gemm(h, g));
+        if (h->cb.on) CHK(cb_mult(h, dagger ? CB_LEFT_BDAG : CB_LEFT_B, k, cur, oth, stab ? D : nullptr));
+        else {
+            GemmArgs g = dagger ? gemm_base(h, C_(h, h->eT2), 1, U_(h, cur), 0, oth)
+                                : gemm_base(h, C_(h, h->eT2), 0, U_(h, cur), 0, oth);
+            if (dagger) { g.rowscale = vs_conf(h, k, +1); g.row_first = 1; }
+            else g.kscale = vs_conf(h, k, +1);
+            if (stab) g.colscale = vs_arr(D, n);
+            CHK(run_gemm(h, g));
+        }
         std::swap(cur, oth);
         if (stab) {
             // udt(curr_U, D, tmp1); T = tmp1 * T  (stack.jl:441-444)
@@ -1380,6 +1444,44 @@ int dqmc_get_reduced_stats(dqmc_handle *h, dqmc_stats *out)
     if (!h || !out) return DQMC_ERR_INVALID;
     if (!h->red_valid) return fail(h, DQMC_ERR_STATE, "call dqmc_reduce first");
     *out = h->red_stats;
+    return DQMC_OK;
+}
+
+
+// CheckerboardTrue with the bond-group factors kept sparse on the device (stack.jl:185-235): `n_mats` factors in ELL
+// form (vals / cols [n_mats][n][kmax], 0-based columns, padding val 0), the diagonal exp(-+dtau mu) per block and
+// seven factor sequences (order: B, B^-1, B', X B, X B^-1, X eT, eTinv X; entries index the factor list).
+int dqmc_set_checkerboard(dqmc_handle *h, int32_t kmax, int32_t n_mats, const double *vals, const int32_t *cols,
+                          const double *mu, const double *mu_inv, const int32_t *seqs /* [7][32] */,
+                          const int32_t *lens /* [7] */)
+{
+    ENTER(h);
+    if (kmax < 1 || kmax > 64 || n_mats < 1 || !vals || !cols || !mu || !mu_inv || !seqs || !lens)
+        return fail(h, DQMC_ERR_INVALID, "dqmc_set_checkerboard: bad arguments");
+    const size_t cnt = (size_t)n_mats * h->n * kmax;
+    for (size_t i = 0; i < cnt; ++i)
+        if (cols[i] < 0 || cols[i] >= h->n) return fail(h, DQMC_ERR_INVALID, "dqmc_set_checkerboard: column index out of range");
+    for (int q = 0; q < 7; ++q) {
+        if (lens[q] < 0 || lens[q] > 32) return fail(h, DQMC_ERR_INVALID, "dqmc_set_checkerboard: sequence too long");
+        for (int i = 0; i < lens[q]; ++i)
+            if (seqs[q * 32 + i] < 0 || seqs[q * 32 + i] >= n_mats)
+                return fail(h, DQMC_ERR_INVALID, "dqmc_set_checkerboard: factor index out of range");
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    CHK(dalloc(h, &h->cb.vals, cnt));
+    CHK(dalloc(h, &h->cb.cols, cnt));
+    CHK(dalloc(h, &h->cb.mu, (size_t)h->nb * h->n));
+    CHK(dalloc(h, &h->cb.mu_inv, (size_t)h->nb * h->n));
+    HIPCHK(hipMemcpy(h->cb.vals, vals, cnt * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->cb.cols, cols, cnt * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->cb.mu, mu, (size_t)h->nb * h->n * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->cb.mu_inv, mu_inv, (size_t)h->nb * h->n * sizeof(double), hipMemcpyHostToDevice));
+    h->cb.kmax = kmax; h->cb.n_mats = n_mats;
+    for (int q = 0; q < 7; ++q) {
+        h->cb.len[q] = lens[q];
+        for (int i = 0; i < lens[q]; ++i) h->cb.seq[q][i] = seqs[q * 32 + i];
+    }
+    h->cb.on = true;
     return DQMC_OK;
 }
 

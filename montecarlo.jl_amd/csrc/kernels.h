@@ -186,6 +186,29 @@ hipError_t launch_sweep_flush_lu(int n, int n_units, const double *Gin, double *
                                  int nsites, const double *img, hipStream_t s, hipEvent_t start = nullptr,
                                  hipEvent_t stop = nullptr);
 
+// Checkerboard products with sparse bond-group factors (cb.hip): O = post . F_last ... F_first . pre . X on the rows
+// (side 0) or columns (side 1) of X; factor m in ELL form vals / cols [m][n][kmax]; the diagonal scalings are the
+// conf-derived exp(+-lambda s) (sign +1 / -1, 0 = none) and / or a stored vector per block (mu); qscale scales the
+// other index (the Diagonal(D) of add_slice_sequence_left/right).
+struct CbArgs {
+    int n, nb, side, kmax, seq_len;
+    int seq[32];
+    const double *vals;
+    const int *cols;
+    const double *X;
+    double *O;
+    long strideX;
+    const int8_t *conf;   // already offset to the slice
+    long conf_stride;
+    double epl, eml;
+    int pre_conf, post_conf;
+    const double *pre_vec, *post_vec;   // [nb][n] or null
+    const double *qscale;               // [units][qstride] or null
+    long qstride;
+};
+hipError_t launch_cb_apply(const CbArgs &a, int n_units, hipStream_t s, hipEvent_t start = nullptr,
+                           hipEvent_t stop = nullptr);
+
 // small helpers
 hipError_t launch_set_identity(int n, int count, double *A, long stride, hipStream_t s);
 hipError_t launch_fill(double *p, size_t n, double v, hipStream_t s);

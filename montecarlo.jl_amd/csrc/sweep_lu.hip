@@ -251,7 +251,7 @@ __global__ __launch_bounds__(64) void sweep_lu_kernel(int n, const double *__res
 // In block I0 wave I0 is the PIVOT: it runs the decisions on its diagonal tiles and publishes, per accepted site,
 // the two A operands (x G[:, s], x G[s, :] on the block's rows) through LDS; waves J > I0 apply them to their strip
 // tiles (I0, J), exchange the finished strip rows once per panel and do the k = 4 updates of their later tiles;
-// wave (I0 + 1) % 4 also carries the two triangular inverses of the diagonal block.  Each slot of the step ring is
+// wave (I0 + 2) % 4 also carries the two triangular inverses of the diagonal block.  Each slot of the step ring is
 // written once per launch (no reuse), flags are LDS words with workgroup-scope release / acquire; every wait is
 // bounded (a time-out sets *errflag and lets all waves run through).
 constexpr int LU4_SPIN = 1 << 21;
@@ -447,14 +447,24 @@ __device__ __noinline__ void lu4_wave(int n, const double *__restrict__ Gall, lo
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     LU4_STAMP(320 + 8 * J + 1);
 #endif
-    const double g0 = sc.gamma[0], g1 = sc.gamma[1], e0 = sc.ebos[0], e1 = sc.ebos[1];
-    const double du0 = sc.dup[0], du1 = sc.dup[1], dd0 = sc.ddn[0], dd1 = sc.ddn[1];
+    // model constants as scalars (arguments of a non-inlined function arrive in vector registers): the per-site
+    // selects then run on the scalar unit
+    auto sgpr = [](double v) {
+        const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(u & 0xffffffffull));
+        const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(u >> 32));
+        return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    };
+    const double g0 = sgpr(sc.gamma[0]), g1 = sgpr(sc.gamma[1]), e0 = sgpr(sc.ebos[0]), e1 = sgpr(sc.ebos[1]);
+    const double du0 = sgpr(sc.dup[0]), du1 = sgpr(sc.dup[1]), dd0 = sgpr(sc.ddn[0]), dd1 = sgpr(sc.ddn[1]);
     int lastflag = 0;  // the newest step word seen (carries the draw counter from pivot to pivot)
 
 #pragma unroll
     for (int I0 = 0; I0 < 4; ++I0) {
         if (!FULL && 16 * I0 >= nsites) break;
-        const bool PIV = (I0 == J), HLP = (J > I0), PTQ = (J == ((I0 + 1) & 3));
+        // the triangular inverses ride on wave I0 + 2: not on the next pivot (I0 + 1), whose lag at the end of the
+        // block is the hand-over time
+        const bool PIV = (I0 == J), HLP = (J > I0), PTQ = (J == ((I0 + 2) & 3));
         if (!PIV && !HLP && !PTQ) continue;
         d4 PT[NB], Q[NB];
         if (PTQ) {

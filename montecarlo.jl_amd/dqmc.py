@@ -62,7 +62,7 @@ def hopping_exponentials(T, delta_tau):
     return eT, eTinv, eT @ eT, eTinv @ eTinv
 
 
-def checkerboard_exponentials(T, lattice, delta_tau):
+def checkerboard_exponentials(T, lattice, delta_tau, return_factors=False):
     """CheckerboardTrue (init_checkerboard_matrices, stack.jl:185-235; slice_matrices.jl:79-222;
     _greens! DQMC.jl:731-750) as the four constant matrices of the dense code path.  The reference
     keeps one sparse matrix per bond group, chkr_hop_half[g] = exp(-dtau/2 Tg) with
@@ -96,6 +96,9 @@ def checkerboard_exponentials(T, lattice, delta_tau):
     mus = np.diag(T)
     Mu, Muinv = np.diag(np.exp(-delta_tau * mus)), np.diag(np.exp(delta_tau * mus))
 
+    if return_factors:
+        return H, Hinv, Cm, Cinv, np.exp(-delta_tau * mus), np.exp(delta_tau * mus), n_groups
+
     def sandwich(half, full):  # the factor applied by multiply_slice_matrix_left! (slice_matrices.jl:109-121)
         M = np.eye(N)
         for i in reversed(range(1, n_groups)):
@@ -113,6 +116,40 @@ def checkerboard_exponentials(T, lattice, delta_tau):
     for i in reversed(range(n_groups)):     # chkr_hop_half_inv[i] * target, i = n..1
         eTinv = Hinv[i] @ eTinv
     return eT, eTinv, P @ Mu, Muinv @ Pinv
+
+
+def checkerboard_tables(T, lattice, delta_tau):
+    """The sparse factors of init_checkerboard_matrices (stack.jl:185-235) in the ELL form dqmc_set_checkerboard takes:
+    factor list = [H_1..H_n, C_1, Hinv_1..Hinv_n, Cinv_1] followed by their transposes (offset n_f), each as
+    (vals, cols)[n_sites][kmax]; plus the seven sequences of include/dqmc_hip.h (0-based factor indices)."""
+    H, Hinv, Cm, Cinv, mu, mu_inv, ng = checkerboard_exponentials(T, lattice, delta_tau, return_factors=True)
+    mats = list(H) + [Cm[0]] + list(Hinv) + [Cinv[0]]
+    nf = len(mats)
+    mats = mats + [m.T for m in mats]
+    N = T.shape[0]
+    kmax = max(int((np.abs(m) > 0).sum(axis=1).max()) for m in mats)
+    vals = np.zeros((len(mats), N, kmax))
+    cols = np.zeros((len(mats), N, kmax), dtype=np.int32)
+    for i, m in enumerate(mats):
+        for r in range(N):
+            nz = np.nonzero(m[r])[0]
+            vals[i, r, :len(nz)] = m[r, nz]
+            cols[i, r, :len(nz)] = nz
+            cols[i, r, len(nz):] = r
+    iH = lambda g: g              # H_g (g = 0..ng-1)
+    iC = ng                       # C_1
+    iHi = lambda g: ng + 1 + g    # Hinv_g
+    iCi = 2 * ng + 1              # Cinv_1
+    sand = lambda h, c: [h(g) for g in range(ng - 1, 0, -1)] + [c] + [h(g) for g in range(1, ng)]
+    tr = lambda seq: [nf + i for i in seq]
+    seqs = [sand(iH, iC),                                 # B X
+            sand(iHi, iCi),                               # B^-1 X
+            tr(sand(iH, iC)),                             # B' X
+            tr(sand(iH, iC)),                             # X B  (columns mixed by rows of the transposes)
+            tr(sand(iHi, iCi)),                           # X B^-1
+            tr([iH(g) for g in range(ng - 1, -1, -1)]),   # X eT = X H_n ... H_1
+            [iHi(g) for g in range(ng - 1, -1, -1)]]      # eTinv X = Hinv_1 ... Hinv_n X (Hinv_n applied first)
+    return dict(kmax=kmax, vals=vals, cols=cols, mu=mu, mu_inv=mu_inv, seqs=seqs)
 
 
 class DQMCAnalysis:
@@ -161,6 +198,26 @@ class DQMC:
                           model.U, dptr(self._eT), dptr(self._eTinv), dptr(self._eT2), dptr(self._eTinv2))
         self._h = C.c_void_p()
         check(lib().dqmc_create(C.byref(prm), C.byref(self._h)))
+        # checkerboard=True picks the faster execution of the same decomposition: measured on MI355X (config 3 shape,
+        # tools/time_checkerboard.py) the sparse-factor kernel takes 32.5 us per product against 31.2 us for the dense
+        # MFMA GEMM with the multiplied-out constants at n = 256, so dense up to n = 256 and sparse (O(n^2) work per
+        # product) above; checkerboard="sparse" / "dense" force one
+        sparse = checkerboard == "sparse" or (checkerboard is True and self.N > 256)
+        if self.checkerboard and sparse:
+            tb = [checkerboard_tables(T, model.l, self.p.delta_tau) for T in Ts]
+            t0 = tb[0]  # both spin blocks of the repulsive model share T (HubbardModelRepulsive.jl:87-100)
+            seqs = np.zeros((7, 32), dtype=np.int32)
+            lens = np.zeros(7, dtype=np.int32)
+            for q, sq in enumerate(t0["seqs"]):
+                lens[q] = len(sq)
+                seqs[q, :len(sq)] = sq
+            mu = np.ascontiguousarray(np.concatenate([t["mu"] for t in tb]))
+            mui = np.ascontiguousarray(np.concatenate([t["mu_inv"] for t in tb]))
+            vals, cols = np.ascontiguousarray(t0["vals"]), np.ascontiguousarray(t0["cols"])
+            check(lib().dqmc_set_checkerboard(self._h, t0["kmax"], vals.shape[0], dptr(vals),
+                                              cols.ctypes.data_as(C.POINTER(C.c_int32)), dptr(mu), dptr(mui),
+                                              seqs.ctypes.data_as(C.POINTER(C.c_int32)),
+                                              lens.ctypes.data_as(C.POINTER(C.c_int32))), self._h)
         # rand(DQMC, m, slices) per walker (DQMC.jl:273), then the Metropolis stream
         self.seeds = [seed + first_walker + w for w in range(n_walkers)]
         for w, s in enumerate(self.seeds):

@@ -118,7 +118,7 @@ def test_checkerboard_chain_on_the_oracle(O, mc_amd):
 def test_checkerboard_on_device(gpu, O, kind):
     L = 4
     model = (gpu.HubbardModelAttractive if kind == "attractive" else gpu.HubbardModelRepulsive)(L, 2)
-    mc = gpu.DQMC(model, beta=2.0, n_walkers=2, seed=17, checkerboard=True)
+    mc = gpu.DQMC(model, beta=2.0, n_walkers=2, seed=17, checkerboard="sparse")
     ex = gpu.checkerboard_exponentials(model.hopping_matrix()[0], model.l, 0.1)
     refs = []
     for w in range(2):
@@ -146,3 +146,64 @@ def test_checkerboard_on_device(gpu, O, kind):
     assert 1e-6 < d < 1.0
     for x in (mc, md, mc2):
         x.close()
+
+
+def test_sparse_factor_tables_reproduce_the_dense_constants(mc_amd):
+    """checkerboard_tables (ELL factors + sequences handed to dqmc_set_checkerboard) against the multiplied-out
+    constants: applying sequence q factor by factor equals the dense product"""
+    dtau = 0.1
+    for model in (mc_amd.HubbardModelAttractive(4, 2, mu=0.3), mc_amd.HubbardModelRepulsive(6, 2)):
+        T = model.hopping_matrix()[0]
+        N = T.shape[0]
+        tb = mc_amd.checkerboard_tables(T, model.l, dtau)
+        eT, eTinv, eT2, eTinv2 = mc_amd.checkerboard_exponentials(T, model.l, dtau)
+        def dense(i):
+            m = np.zeros((N, N))
+            for r in range(N):
+                for j in range(tb["kmax"]):
+                    m[r, tb["cols"][i, r, j]] += tb["vals"][i, r, j]
+            return m
+        def left(seq):
+            M = np.eye(N)
+            for i in seq:
+                M = dense(i) @ M
+            return M
+        def right(seq):   # columns mixed by the rows of the stored (transposed) factors
+            M = np.eye(N)
+            for i in seq:
+                M = M @ dense(i).T
+            return M
+        Mu, Mui = np.diag(tb["mu"]), np.diag(tb["mu_inv"])
+        s = tb["seqs"]
+        assert np.abs(left(s[0]) @ Mu - eT2).max() < 1e-13          # B / eV
+        assert np.abs(Mui @ left(s[1]) - eTinv2).max() < 1e-13      # eV B^-1
+        assert np.abs(Mu @ left(s[2]) - eT2.T).max() < 1e-13        # B' / eV
+        assert np.abs(right(s[3]) @ Mu - eT2).max() < 1e-13         # X B
+        assert np.abs(Mui @ right(s[4]) - eTinv2).max() < 1e-13     # X B^-1
+        assert np.abs(right(s[5]) - eT).max() < 1e-13
+        assert np.abs(left(s[6]) - eTinv).max() < 1e-13
+        assert tb["kmax"] <= 4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,L", [("attractive", 4), ("repulsive", 4), ("attractive", 8)])
+def test_sparse_and_dense_checkerboard_paths_agree(gpu, kind, L):
+    """the sparse-factor kernel (cb.hip) against the same decomposition run through the dense MFMA path"""
+    model = (gpu.HubbardModelAttractive if kind == "attractive" else gpu.HubbardModelRepulsive)(L, 2)
+    a = gpu.DQMC(model, beta=2.0, n_walkers=2, seed=3, checkerboard="sparse")
+    b = gpu.DQMC(model, beta=2.0, n_walkers=2, seed=3, checkerboard="dense")
+    a.prepare(); b.prepare()
+    for _ in range(3):
+        for w in range(2):
+            for blk in range(a.nb):
+                ga, gb = a.greens_eff(w)[blk], b.greens_eff(w)[blk]
+                assert np.abs(ga - gb).max() < 1e-11 * max(1.0, np.abs(gb).max())
+                ga, gb = a.greens(w)[blk], b.greens(w)[blk]
+                assert np.abs(ga - gb).max() < 1e-11 * max(1.0, np.abs(gb).max())
+        a.sweep(1); b.sweep(1)
+        for w in range(2):
+            assert np.array_equal(a.conf(w), b.conf(w))
+    ga = a.calculate_greens(7, 0)[0]
+    gb = b.calculate_greens(7, 0)[0]
+    assert np.abs(ga - gb).max() < 1e-11 * max(1.0, np.abs(gb).max())
+    a.close(); b.close()

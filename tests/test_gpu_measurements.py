@@ -79,30 +79,97 @@ def test_pairing_requires_tables(gpu):
     mc.close()
 
 
-def test_reference_integration_goldens_on_the_device(gpu):
-    """End to end on the GPU against numbers produced by the reference itself
-    (test/integration_tests.jl:29-75: attractive 4x4, beta = 1; the published means of one seeded
-    Julia run with atol = 4 dtau^2 = 0.04): 32 walkers x 60 measured sweeps, everything - sweeps,
-    true Green's function, charge / spin density correlations over EachSitePairByDistance - on the
-    device through run().  The golden's own standard error reaches 0.019 (integration_tests.jl:50-52)."""
-    import json, os
-    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "integration_attractive_4x4.json")))
-    model = gpu.HubbardModelAttractive(4, 2)
-    mc = gpu.DQMC(model, beta=1.0, n_walkers=32, seed=2024, thermalization=50, sweeps=60, measure_rate=1)
-    mc.set_pair_directions(gpu.EachSitePairByDistance(model.l))
-    mc.run(measurements=("greens", "correlations"))
-    acc = mc.unpack_accumulators(mc.accumulators())
-    assert acc["count"] == 32 * 60
-    ref = np.array(g["G_mean_colmajor"]).reshape((16, 16), order="F")
-    assert np.abs(acc["G"][0] - ref).max() < g["atol"] + 0.02
-    c = mc.correlations()
-    assert c["count"] == 32 * 60
-    assert np.abs(c["CDC"] - np.array(g["CDC_mean"])).max() < g["atol"] + 0.02
-    assert np.abs(c["SDCx"] - np.array(g["SDCx_mean"])).max() < g["atol"]
-    # structure the reference's result has: on-site first, then four symmetry-equivalent neighbours
-    assert c["CDC"][0] > 1.4 and np.ptp(c["CDC"][1:5]) < 0.02
-    assert np.abs(c["Mz"]).max() == 0.0
+def _device_blocks(gpu, kind, L, K, n_walkers, blocks, per_block, therm, seed):
+    """block means of every observable of the reference's integration testsets, measured on the device (true Green's
+    function, correlations over EachSitePairByDistance, pairing over EachLocalQuadByDistance{K}, the HS field)"""
+    model = (gpu.HubbardModelAttractive if kind == "attractive" else gpu.HubbardModelRepulsive)(L, 2)
+    mc = gpu.DQMC(model, beta=1.0, n_walkers=n_walkers, seed=seed)
+    mc.set_local_targets(gpu.EachLocalQuadByDistance(model.l, K))
+    mc.prepare()
+    for _ in range(therm):
+        mc.update_until_measure()
+    mc.reset_accumulators()
+    N, nb = L * L, mc.nb
+    ser = {k: [] for k in ("G", "conf", "CDC", "SDCx", "SDCy", "SDCz", "Mx", "My", "Mz", "PC")}
+    prev_acc, prev_corr, prev_pc = np.zeros(mc.accumulator_size()), None, None
+    nd = None
+    for _ in range(blocks):
+        for _ in range(per_block):
+            mc.update_until_measure()
+            mc.accumulate_greens(); mc.accumulate_correlations(); mc.accumulate_pairing()
+        acc, corr = mc.accumulators(), mc.correlations_raw()
+        pc_mean, pc_cnt = mc.pairing()
+        pc = pc_mean * pc_cnt
+        if prev_corr is None:
+            prev_corr, prev_pc = np.zeros_like(corr), np.zeros_like(pc)
+            nd = (len(corr) - 1 - 3 * N) // 4
+        cnt = acc[-1] - prev_acc[-1]
+        dG = (acc - prev_acc)[:nb * N * N] / cnt
+        ser["G"].append(np.stack([dG[b * N * N:(b + 1) * N * N].reshape((N, N), order="F") for b in range(nb)]))
+        dc = (corr - prev_corr) / (corr[-1] - prev_corr[-1])
+        for i, k in enumerate(("CDC", "SDCx", "SDCy", "SDCz")):
+            ser[k].append(dc[i * nd:(i + 1) * nd])
+        for i, k in enumerate(("Mx", "My", "Mz")):
+            ser[k].append(dc[4 * nd + i * N:4 * nd + (i + 1) * N])
+        ser["PC"].append((pc - prev_pc) / per_block / n_walkers)
+        ser["conf"].append(np.mean([mc.conf(w).astype(float) for w in range(n_walkers)], axis=0))
+        prev_acc, prev_corr, prev_pc = acc, corr, pc
     mc.close()
+    return {k: np.array(v) for k, v in ser.items()}
+
+
+def _block_error(x):
+    return x.std(axis=0, ddof=1) / np.sqrt(x.shape[0])
+
+
+def test_reference_integration_goldens_on_the_device(gpu):
+    """End to end on the GPU against EVERY number the reference holds for its two seeded DQMC integration runs
+    (test/integration_tests.jl:29-94 attractive 4x4, :98-185 repulsive 2x2): mean G, mean HS field, CDC, SDCx/y/z,
+    Mx/y/z, PC.  32 walkers; rules of tests/golden_stats.py (the reference's own atol, unwidened, wherever its own
+    published std_error allows it - everywhere for CDC / SDC / PC / M - and a z-score against the published std_error
+    for every element)."""
+    import golden_stats as gs
+    g = gs.load("integration_attractive_4x4.json")
+    A, atol = g["all"], g["atol"]
+    s = _device_blocks(gpu, "attractive", 4, 5, 32, 24, 8, 30, 2024)
+    m, se = gs.golden_arrays(A["G"], (16, 16))
+    r = gs.check("att G", s["G"][:, 0].mean(0), _block_error(s["G"][:, 0]), m, se, atol)
+    assert r["n_at_ref_atol"] >= 200
+    m, _ = gs.golden_arrays(A["conf"])
+    gs.check("att conf", s["conf"].mean(0), _block_error(s["conf"]), m,
+             np.sqrt(np.maximum(1 - m ** 2, 0.0) / g["n_measurements"]), atol)
+    for k in ("CDC", "SDCx", "SDCy", "SDCz"):
+        m, se = gs.golden_arrays(A[k])
+        r = gs.check("att " + k, s[k].mean(0), _block_error(s[k]), m, se, atol, all_at_atol=True)
+        assert r["n_at_ref_atol"] == 16
+    m, se = gs.golden_arrays(A["PC"], (16, 5, 5))
+    r = gs.check("att PC", s["PC"].mean(0).reshape((16, 5, 5), order="F"),
+                 _block_error(s["PC"]).reshape((16, 5, 5), order="F"), m, se, atol, all_at_atol=True, zmax=6.5)
+    assert r["n_at_ref_atol"] == 400
+    assert np.abs(s["Mz"]).max() == 0.0  # attractive: identical spin blocks
+    # structure the reference's result has: on-site first, then four symmetry-equivalent neighbours
+    cdc = s["CDC"].mean(0)
+    assert cdc[0] > 1.4 and np.ptp(cdc[1:5]) < 0.02
+
+    g = gs.load("integration_repulsive_2x2.json")
+    A, atol = g["all"], g["atol"]
+    s = _device_blocks(gpu, "repulsive", 2, 3, 32, 24, 8, 30, 2025)
+    m, se = gs.golden_arrays(A["G"])
+    ours = np.zeros((8, 8)); ours_se = np.zeros((8, 8))
+    for b in range(2):
+        ours[4 * b:4 * b + 4, 4 * b:4 * b + 4] = s["G"][:, b].mean(0)
+        ours_se[4 * b:4 * b + 4, 4 * b:4 * b + 4] = _block_error(s["G"][:, b])
+    gs.check("rep G", ours, ours_se, m, se, atol)
+    m, _ = gs.golden_arrays(A["conf"])
+    gs.check("rep conf", s["conf"].mean(0), _block_error(s["conf"]), m,
+             np.sqrt(np.maximum(1 - m ** 2, 0.0) / g["n_measurements"]), atol)
+    for k in ("CDC", "Mx", "My", "Mz", "SDCx", "SDCy", "SDCz"):
+        m, se = gs.golden_arrays(A[k])
+        gs.check("rep " + k, s[k].mean(0), _block_error(s[k]), m, se, atol if A[k]["has_atol"] else None,
+                 all_at_atol=True)
+    m, se = gs.golden_arrays(A["PC"], (4, 3, 3))
+    gs.check("rep PC", s["PC"].mean(0).reshape((4, 3, 3), order="F"),
+             _block_error(s["PC"]).reshape((4, 3, 3), order="F"), m, se, None)
 
 
 def test_run_with_all_measurements(gpu):
