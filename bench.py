@@ -5,7 +5,8 @@ Workloads (BASELINE.json `configs`), selected with --config:
   3 (default, the configuration the metric is quoted on): attractive Hubbard 16x16, beta=8, dtau=0.1
     (n=256, M=80, K=8), 32 walkers per MI355X — weak scaling (N GPUs run N x 32 walkers);
   4: repulsive Hubbard 16x16, beta=8: 256 walkers in total, split over WORLD_SIZE — strong scaling;
-  5: attractive Hubbard 24x24, beta=20, dtau=0.05 (n=576, M=400, K=40), 64 walkers per GPU — weak scaling.
+  5: attractive Hubbard 24x24, beta=20, dtau=0.05 (n=576, M=400, K=40), 256 walkers per GPU (64 GB of the 288 GB:
+     one workgroup per matrix in the n > 256 QR fills the 256 CUs) — weak scaling.
 
 One "step" = one sweep (2*slices `update` calls, src/flavors/DQMC/DQMC.jl:422-437) of every walker resident on the
 rank.  Walkers are independent Markov chains: there is no data-path collective, only the RCCL all-reduce of the
@@ -38,7 +39,7 @@ CONFIGS = {
             name="attractive Hubbard 16x16, beta=8, dtau=0.1 (n=256, M=80, safe_mult=10)"),
     4: dict(model="repulsive", L=16, beta=8.0, dtau=0.1, walkers=None, total=256, scaling="strong", steps=4, warmup=1,
             name="repulsive Hubbard 16x16, beta=8, dtau=0.1 (2 blocks of n=256, M=80, safe_mult=10), 256 walkers in total"),
-    5: dict(model="attractive", L=24, beta=20.0, dtau=0.05, walkers=64, total=None, scaling="weak", steps=2, warmup=1,
+    5: dict(model="attractive", L=24, beta=20.0, dtau=0.05, walkers=256, total=None, scaling="weak", steps=2, warmup=1,
             name="attractive Hubbard 24x24, beta=20, dtau=0.05 (n=576, M=400, safe_mult=10)"),
 }
 SAFE_MULT = 10

@@ -45,6 +45,7 @@ struct dqmc_handle {
     double *tmp1 = nullptr, *tmp2 = nullptr, *bufA = nullptr, *bufB = nullptr;
     double *qrV = nullptr, *qrW = nullptr, *qrS = nullptr;
     double *trsm_w = nullptr;  // inverted 16 x 16 diagonal blocks (launch_trsm_right_upper)
+    double *trsm_s = nullptr;  // n > 256: gathered / panel-solved copy of the right-hand side
     double *Dl = nullptr, *Dr = nullptr, *tau = nullptr;
     int *pivot = nullptr;
     double *sU = nullptr, *sVT = nullptr;
@@ -324,7 +325,7 @@ static int udt(dqmc_handle *h, double *A, double *Uout, double *Dout, double *To
     {
         Timed t(h, DQMC_K_TRSM);
         HIPCHK(launch_trsm_right_upper(n, h->units, h->qrV, h->nn, h->qrS, h->nn, nullptr, h->tau, n, h->qrW, h->nn,
-                                       h->trsm_w, h->stream));
+                                       h->trsm_w, h->stream, h->trsm_s));
     }
     g = gemm_base(h, U_(h, h->qrW), 0, U_(h, h->qrV), 1, Uout);
     g.alpha = -1.0;
@@ -336,7 +337,7 @@ static int rdivp(dqmc_handle *h, double *A, const double *T)
 {
     Timed t(h, DQMC_K_TRSM);
     HIPCHK(launch_trsm_right_upper(h->n, h->units, A, h->nn, T, h->nn, h->pivot, nullptr, 0, A, h->nn, h->trsm_w,
-                                   h->stream));
+                                   h->stream, h->trsm_s));
     return 0;
 }
 
@@ -770,6 +771,7 @@ int dqmc_create(const dqmc_params *p, dqmc_handle **out)
     for (auto m : mats) CCHK(dalloc(h, m, un));
     CCHK(dalloc(h, &h->Dl, uv)); CCHK(dalloc(h, &h->Dr, uv)); CCHK(dalloc(h, &h->tau, uv));
     CCHK(dalloc(h, &h->trsm_w, (size_t)h->units * ((h->n + 15) / 16) * 256));
+    if (h->n > 256) CCHK(dalloc(h, &h->trsm_s, un));
     CCHK(dalloc(h, &h->pivot, uv));
     CCHK(alloc_qr_workspace(h));
     CCHK(dalloc(h, &h->sU, (size_t)h->units * h->n * h->kd));

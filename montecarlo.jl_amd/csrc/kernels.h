@@ -108,9 +108,11 @@ hipError_t launch_udt_finish(int n, int n_units, double *A, long strideA, const 
 // compact-WY triangle, whose inverse diagonal is tau).
 hipError_t launch_trsm_right_upper(int n, int n_units, const double *A, long strideA, const double *T,
                                    long strideT, const int *pivot, const double *dmul, long strideV,
-                                   double *Out, long strideOut, double *winv, hipStream_t s);
+                                   double *Out, long strideOut, double *winv, hipStream_t s,
+                                   double *scratch = nullptr);
 // winv: n_units * ceil(n/16) * 256 doubles of scratch for the inverted diagonal blocks (n <= 256 path);
-// nullptr selects the substitution kernel
+// nullptr selects the substitution kernel; scratch: n_units x strideOut doubles for the panelled MFMA solve of n > 256
+// (without it the substitution kernel is used there)
 
 // One chunk of sweep_spatial (DQMC.jl:546-582): sites [site0, site0+nsites) of the
 // current slice with delayed rank-1 updates; writes the accepted update vectors

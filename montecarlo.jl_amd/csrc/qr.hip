@@ -1052,6 +1052,7 @@ __global__ __launch_bounds__(16) void trsm_diag_inv_kernel(int n, const double *
                                                           const double *__restrict__ dmulall, long sV,
                                                           double *__restrict__ Wall, int nblk)
 {
+    // (n, nblk: the whole matrix; every 16 x 16 diagonal block of it is inverted, also for the panelled solve)
     __shared__ double B[16][17], rdg[16];
     const int J = blockIdx.x, unit = blockIdx.y, j = threadIdx.x, j0 = J << 4;
     const double *__restrict__ T = Tall + (long)unit * sT;
@@ -1073,7 +1074,12 @@ __global__ __launch_bounds__(16) void trsm_diag_inv_kernel(int n, const double *
     for (int i = 0; i < 16; ++i) W[i + 16 * j] = wcol[i];  // column-major 16 x 16
 }
 
-__global__ __launch_bounds__(128) void trsm_mfma_kernel(int n, const double *__restrict__ Aall, long sA,
+// Panel form: solves the nc columns c0 .. c0 + nc - 1 (nc <= 256) of an nr-row problem against the diagonal block
+// T[c0 : c0 + nc, c0 : c0 + nc] of an ld x ld triangle; the contribution of the columns before c0 must already have
+// been subtracted (launch_trsm_right_upper does that with a GEMM for n > 256).  nr = nc = ld = n, c0 = 0 is the
+// whole n <= 256 problem.
+__global__ __launch_bounds__(128) void trsm_mfma_kernel(int nr, int n, int c0, int ld, int nblk_all,
+                                                       const double *__restrict__ Aall, long sA,
                                                        const double *__restrict__ Tall, long sT,
                                                        const int *__restrict__ pivall,
                                                        const double *__restrict__ dmulall, long sV,
@@ -1086,8 +1092,8 @@ __global__ __launch_bounds__(128) void trsm_mfma_kernel(int n, const double *__r
     double *Wl = Tp + 16 * TM_TS;      // [16][18] inverse of the current diagonal block, W[k][c] at Wl + c*18 + k
     const int unit = blockIdx.x / slabs, row0 = (blockIdx.x % slabs) * 32;
     const double *__restrict__ A = Aall + (long)unit * sA;
-    const double *__restrict__ T = Tall + (long)unit * sT;
-    const int *__restrict__ piv = pivall ? pivall + (long)unit * n : nullptr;
+    const double *__restrict__ T = Tall + (long)unit * sT + (long)ld * c0 + c0;  // the panel's diagonal block
+    const int *__restrict__ piv = pivall ? pivall + (long)unit * ld : nullptr;
     (void)dmulall; (void)sV;  // the diagonal enters through the inverted blocks
     double *__restrict__ O = Oall + (long)unit * sO;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -1095,12 +1101,12 @@ __global__ __launch_bounds__(128) void trsm_mfma_kernel(int n, const double *__r
 
     for (int idx = tid; idx < n * 32; idx += 128) {
         const int j = idx >> 5, r = idx & 31, row = row0 + r;
-        const int pj = piv ? piv[j] : j;
-        Xs[j * TM_XS + r] = row < n ? A[row + (long)n * pj] : 0.0;
+        const int pj = piv ? piv[c0 + j] : c0 + j;
+        Xs[j * TM_XS + r] = row < nr ? A[row + (long)ld * pj] : 0.0;
     }
     const int nblk = (n + 15) >> 4;
     for (int idx = n * 32 + tid; idx < nblk * 16 * 32; idx += 128) Xs[(idx >> 5) * TM_XS + (idx & 31)] = 0.0;  // columns >= n
-    const double *__restrict__ Wu = Wall + (long)unit * nblk * 256;
+    const double *__restrict__ Wu = Wall + ((long)unit * nblk_all + (c0 >> 4)) * 256;
     // the T panel of block J+1 is requested from global memory (L2) while block J computes:
     // thread (c = tid >> 3) holds k = (tid & 7) + 8 i of column j0 + c in registers until the LDS panel is free
     double pre[32], pre_w[2] = {0.0, 0.0};
@@ -1110,7 +1116,7 @@ __global__ __launch_bounds__(128) void trsm_mfma_kernel(int n, const double *__r
         // the number of 8-row steps is wave-uniform
         const int j0 = J << 4, c = tid >> 3, col = min(j0 + c, n - 1);
         const int steps = J < nblk ? ((min(j0 + 16, n) + 15) >> 4) << 1 : 0;  // 8-row steps, rounded up to a pair
-        const double *__restrict__ tc = T + (long)n * col;
+        const double *__restrict__ tc = T + (long)ld * col;
 #pragma unroll
         for (int i = 0; i < 32; i += 2) {
             if (i < steps) {  // one wave-uniform guard per pair
@@ -1178,27 +1184,80 @@ __global__ __launch_bounds__(128) void trsm_mfma_kernel(int n, const double *__r
     __syncthreads();
     for (int idx = tid; idx < n * 32; idx += 128) {
         const int j = idx >> 5, r = idx & 31, row = row0 + r;
-        if (row < n) O[row + (long)n * j] = Xs[j * TM_XS + r];
+        if (row < nr) O[row + (long)ld * (c0 + j)] = Xs[j * TM_XS + r];
+    }
+}
+
+// W[:, j] = A[:, pivot[j]] (the gather of rdivp!, general.jl:143-148) for the panelled solve
+__global__ void trsm_gather_kernel(int n, const double *__restrict__ Aall, long sA, const int *__restrict__ pivall,
+                                   double *__restrict__ Wall, long sW)
+{
+    const int unit = blockIdx.y;
+    const double *__restrict__ A = Aall + (long)unit * sA;
+    double *__restrict__ W = Wall + (long)unit * sW;
+    const int *__restrict__ piv = pivall ? pivall + (long)unit * n : nullptr;
+    const long nn = (long)n * n;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < nn; idx += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(idx % n), c = (int)(idx / n);
+        W[idx] = A[r + (long)n * (piv ? piv[c] : c)];
     }
 }
 
 hipError_t launch_trsm_right_upper(int n, int n_units, const double *A, long sA, const double *T, long sT,
                                    const int *pivot, const double *dmul, long sV, double *Out, long sO,
-                                   double *winv, hipStream_t s)
+                                   double *winv, hipStream_t s, double *scratch)
 {
     static const bool no_mfma = getenv("DQMC_TRSM_SIMPLE") != nullptr;
+    const size_t lds_m = (256 * TM_XS + 16 * TM_TS + 16 * 18) * sizeof(double);
+    auto set_attr = [&]() {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        static unsigned attr_mask = 0;  // per device
+        if (!(attr_mask & (1u << dev))) {
+            (void)hipFuncSetAttribute((const void *)trsm_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds_m);
+            attr_mask |= 1u << dev;
+        }
+    };
     if (n <= 256 && winv && !no_mfma) {
         const int slabs = (n + 31) / 32, nblk = (n + 15) / 16;
         hipLaunchKernelGGL(trsm_diag_inv_kernel, dim3(nblk, n_units), dim3(16), 0, s, n, T, sT, dmul, sV, winv, nblk);
-        const size_t lds = (256 * TM_XS + 16 * TM_TS + 16 * 18) * sizeof(double);
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute((const void *)trsm_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)lds);
-            attr_set = true;
+        set_attr();
+        hipLaunchKernelGGL(trsm_mfma_kernel, dim3(n_units * slabs), dim3(128), lds_m, s, n, n, 0, n, nblk, A, sA, T, sT,
+                           pivot, dmul, sV, Out, sO, slabs, winv);
+        return hipGetLastError();
+    }
+    if (n > 256 && winv && scratch && sA == sO && !no_mfma) {
+        // Panels of up to 256 columns: gather (pivot) into scratch, then per panel  X_P = (A_P - X_<P T_<P,P) inv(T_PP):
+        // the bracket with the MFMA GEMM, the triangle with the panel form of the kernel above.
+        const int nblk = (n + 15) / 16, slabs = (n + 31) / 32;
+        int pw = 256;
+        for (int cand = 256; cand >= 128; cand -= 16)  // equal panels when a width between 128 and 256 divides n
+            if (n % cand == 0) { pw = cand; break; }
+        hipLaunchKernelGGL(trsm_diag_inv_kernel, dim3(nblk, n_units), dim3(16), 0, s, n, T, sT, dmul, sV, winv, nblk);
+        int bx = (int)(((long)n * n + 255) / 256);
+        if (bx > 128) bx = 128;
+        hipLaunchKernelGGL(trsm_gather_kernel, dim3(bx, n_units), dim3(256), 0, s, n, A, sA, pivot, scratch, sO);
+        set_attr();
+        for (int c0 = 0; c0 < n; c0 += pw) {
+            const int nc = n - c0 < pw ? n - c0 : pw;
+            if (c0 > 0) {
+                GemmArgs g{};
+                g.M = n; g.N = nc; g.K = c0;
+                g.n_units = n_units; g.nb = 1;
+                g.A = mat(scratch, sO, n);
+                g.B = mat(T + (long)n * c0, sT, n);
+                g.C = scratch + (long)n * c0; g.strideC = sO; g.ldc = n;
+                g.kscale = g.colscale = g.rowscale = g.adddiag = vs_none();
+                g.alpha = -1.0; g.ident = 0.0; g.beta = 1;
+                hipError_t e = launch_gemm(g, s);
+                if (e != hipSuccess) return e;
+            }
+            hipLaunchKernelGGL(trsm_mfma_kernel, dim3(n_units * slabs), dim3(128), lds_m, s, n, nc, c0, n, nblk, scratch, sO,
+                               T, sT, nullptr, dmul, sV, scratch, sO, slabs, winv);
         }
-        hipLaunchKernelGGL(trsm_mfma_kernel, dim3(n_units * slabs), dim3(128), lds, s, n, A, sA, T, sT, pivot, dmul,
-                           sV, Out, sO, slabs, winv);
+        hipError_t e = hipMemcpyAsync(Out, scratch, sizeof(double) * (size_t)n_units * sO, hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) return e;
         return hipGetLastError();
     }
     // slab height: largest of 64/32/16 whose LDS image fits
