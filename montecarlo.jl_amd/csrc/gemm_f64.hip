@@ -55,13 +55,17 @@ __device__ __forceinline__ void tile_load(const double *__restrict__ p, int ld, 
 template <bool KCONTIG>
 __device__ __forceinline__ void tile_store(double (*Xs)[LS], int tid, const double r[4])
 {
+    // columns of row k are rotated by 4 (k >> 2) (mod 64): the transposing store below then spreads the four lanes
+    // that share a column over 16 distinct 8-byte slots (unrotated they hit one bank, rows 4 apart are 640 dwords
+    // apart); the reads of compute() stay conflict free (a row's 16 lanes remain consecutive mod 64)
     if (!KCONTIG) {
-        double *d = &Xs[tid >> 4][(tid & 15) << 2];
+        const int k = tid >> 4;
+        double *d = &Xs[k][(((tid & 15) << 2) + ((k >> 2) << 2)) & 63];
         d[0] = r[0]; d[1] = r[1]; d[2] = r[2]; d[3] = r[3];
     } else {
         const int c = tid >> 2, k = (tid & 3) << 2;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) Xs[k + i][c] = r[i];
+        for (int i = 0; i < 4; ++i) Xs[k + i][(c + k) & 63] = r[i];
     }
 }
 
@@ -148,9 +152,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, int tiles_m, int 
     auto compute = [&](int cur) {
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 4) {
-            const int kq = kk + lq;
-            const double a0 = As[cur][kq][wm + li], a1 = As[cur][kq][wm + 16 + li];
-            const double b0 = Bs[cur][kq][wn + li], b1 = Bs[cur][kq][wn + 16 + li];
+            const int kq = kk + lq, rot = kk;  // rows kk .. kk + 3 share (k >> 2) = kk >> 2: rotation 4 (kk >> 2) = kk
+            const double a0 = As[cur][kq][(wm + li + rot) & 63], a1 = As[cur][kq][(wm + 16 + li + rot) & 63];
+            const double b0 = Bs[cur][kq][(wn + li + rot) & 63], b1 = Bs[cur][kq][(wn + 16 + li + rot) & 63];
             acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a0, acc[0][0], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a1, acc[1][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a0, acc[0][1], 0, 0, 0);

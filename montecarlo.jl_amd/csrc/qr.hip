@@ -1203,6 +1203,11 @@ __global__ void trsm_gather_kernel(int n, const double *__restrict__ Aall, long 
     }
 }
 
+// right-looking register-resident solve (trsm_rl.hip)
+hipError_t launch_trsm_rl(int nr, int nc, int c0, int ld, int nblk_all, int n_units, const double *A, long sA,
+                          const double *T, long sT, const int *pivot, double *Out, long sO, const double *winv,
+                          hipStream_t s);
+
 hipError_t launch_trsm_right_upper(int n, int n_units, const double *A, long sA, const double *T, long sT,
                                    const int *pivot, const double *dmul, long sV, double *Out, long sO,
                                    double *winv, hipStream_t s, double *scratch)
@@ -1223,8 +1228,13 @@ hipError_t launch_trsm_right_upper(int n, int n_units, const double *A, long sA,
         const int slabs = (n + 31) / 32, nblk = (n + 15) / 16;
         hipLaunchKernelGGL(trsm_diag_inv_kernel, dim3(nblk, n_units), dim3(16), 0, s, n, T, sT, dmul, sV, winv, nblk);
         set_attr();
-        hipLaunchKernelGGL(trsm_mfma_kernel, dim3(n_units * slabs), dim3(128), lds_m, s, n, n, 0, n, nblk, A, sA, T, sT,
-                           pivot, dmul, sV, Out, sO, slabs, winv);
+        // (in place is fine for both kernels: a workgroup reads all entries of its own 32 rows before it writes any)
+        static const bool left_looking = getenv("DQMC_TRSM_LL") != nullptr;  // the slab-in-LDS kernel (A/B measurements)
+        if (left_looking)
+            hipLaunchKernelGGL(trsm_mfma_kernel, dim3(n_units * slabs), dim3(128), lds_m, s, n, n, 0, n, nblk, A, sA, T, sT,
+                               pivot, dmul, sV, Out, sO, slabs, winv);
+        else
+            return launch_trsm_rl(n, n, 0, n, nblk, n_units, A, sA, T, sT, pivot, Out, sO, winv, s);
         return hipGetLastError();
     }
     if (n > 256 && winv && scratch && sA == sO && !no_mfma) {
@@ -1253,8 +1263,8 @@ hipError_t launch_trsm_right_upper(int n, int n_units, const double *A, long sA,
                 hipError_t e = launch_gemm(g, s);
                 if (e != hipSuccess) return e;
             }
-            hipLaunchKernelGGL(trsm_mfma_kernel, dim3(n_units * slabs), dim3(128), lds_m, s, n, nc, c0, n, nblk, scratch, sO,
-                               T, sT, nullptr, dmul, sV, scratch, sO, slabs, winv);
+            hipError_t er = launch_trsm_rl(n, nc, c0, n, nblk, n_units, scratch, sO, T, sT, nullptr, scratch, sO, winv, s);
+            if (er != hipSuccess) return er;
         }
         hipError_t e = hipMemcpyAsync(Out, scratch, sizeof(double) * (size_t)n_units * sO, hipMemcpyDeviceToDevice, s);
         if (e != hipSuccess) return e;
