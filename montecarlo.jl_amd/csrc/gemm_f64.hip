@@ -13,6 +13,7 @@
 // column-major C: stores are 128-byte segments.
 #include "kernels.h"
 #include <hip/hip_ext.h>
+#include <cstdlib>
 
 namespace dqmc {
 
@@ -69,8 +70,13 @@ __device__ __forceinline__ void tile_store(double (*Xs)[LS], int tid, const doub
     }
 }
 
+// Barrier of the k-loop: only the LDS tiles are handed between waves there.  __syncthreads() would also wait for
+// the global loads of the tile two steps ahead that were requested a moment earlier (s_waitcnt vmcnt(0)), i.e. put
+// an L2 round trip into every k-step.
+#define GEMM_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
 template <bool TA, bool TB>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, int tiles_m, int tiles_n)
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, int tiles_m, int tiles_n, int gemm_stagger)
 {
     __shared__ double As[2][BK][LS];
     __shared__ double Bs[2][BK][LS];
@@ -162,22 +168,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, int tiles_m, int 
         }
     };
 
+    // The two workgroups that share a CU (grid = 2 per CU at 32 units) run the same program: left alone they reach
+    // their MFMA bursts and their barriers together.  The second half of the grid starts half a k-step late.
+    if (gemm_stagger && blockIdx.x >= (gridDim.x >> 1)) __builtin_amdgcn_s_sleep(16);
     load(0, ra[0], rb[0], ksd[0], ksc[0]);
     store(0, ra[0], rb[0], ksd[0], ksc[0]);
-    __syncthreads();
+    GEMM_LDS_BARRIER();
     if (nk > 1) load(1, ra[1], rb[1], ksd[1], ksc[1]);
     for (int kt = 0; kt < nk; kt += 2) {
         // even tile kt: LDS buffer 0, its registers (slot 0) are free for tile kt+2
         if (kt + 2 < nk) load(kt + 2, ra[0], rb[0], ksd[0], ksc[0]);
         compute(0);
         if (kt + 1 < nk) store(1, ra[1], rb[1], ksd[1], ksc[1]);
-        __syncthreads();
+        GEMM_LDS_BARRIER();
         if (kt + 1 >= nk) break;
         // odd tile kt+1: LDS buffer 1, slot 1 free for tile kt+3
         if (kt + 3 < nk) load(kt + 3, ra[1], rb[1], ksd[1], ksc[1]);
         compute(1);
         if (kt + 2 < nk) store(0, ra[0], rb[0], ksd[0], ksc[0]);
-        __syncthreads();
+        GEMM_LDS_BARRIER();
     }
 
     // epilogue: lane holds C[m = .. + li][n = .. + lq + 4r]
@@ -242,7 +251,8 @@ hipError_t launch_gemm(const GemmArgs &g, hipStream_t s, hipEvent_t start, hipEv
     const int tm = (g.M + BM - 1) / BM, tn = (g.N + BN - 1) / BN;
     const int groups = (g.n_units + 7) / 8;
     dim3 grid(groups * 8 * tm * tn), block(256);
-#define GEMM_LAUNCH(TA, TB) hipExtLaunchKernelGGL((gemm_kernel<TA, TB>), grid, block, 0, s, start, stop, 0, g, tm, tn)
+    static const int stagger = getenv("DQMC_GEMM_STAGGER") ? atoi(getenv("DQMC_GEMM_STAGGER")) : 0;
+#define GEMM_LAUNCH(TA, TB) hipExtLaunchKernelGGL((gemm_kernel<TA, TB>), grid, block, 0, s, start, stop, 0, g, tm, tn, stagger)
     if (g.transA) {
         if (g.transB) GEMM_LAUNCH(true, true);
         else GEMM_LAUNCH(true, false);
