@@ -41,6 +41,9 @@ struct dqmc_handle {
     int8_t *conf = nullptr;  // W x (N x M)
     // stack (slot-major): u/t: (K+1) x units x n^2 ; d: (K+1) x units x n
     double *u_stack = nullptr, *t_stack = nullptr, *d_stack = nullptr;
+    // slot i of the UDT stack = (su[i], sd[i], st[i]); entry K + 1 is a spare: a slot is rewritten by building the new
+    // factors in the spare and swapping the pointers, so the old content stays readable (no load_slot copies)
+    std::vector<double *> su, sd, st;
     double *Ul = nullptr, *Ur = nullptr, *Tl = nullptr, *Tr = nullptr, *greens = nullptr, *greens_temp = nullptr;
     double *tmp1 = nullptr, *tmp2 = nullptr, *bufA = nullptr, *bufB = nullptr;
     double *qrV = nullptr, *qrW = nullptr, *qrS = nullptr;
@@ -246,9 +249,16 @@ static VecSrc vs_conf(dqmc_handle *h, int slice, int sign)
     v.cpos[1] = b; v.cneg[1] = a;
     return v;
 }
-static double *uslot(dqmc_handle *h, int i) { return h->u_stack + (long)i * h->units * h->nn; }
-static double *tslot(dqmc_handle *h, int i) { return h->t_stack + (long)i * h->units * h->nn; }
-static double *dslot(dqmc_handle *h, int i) { return h->d_stack + (long)i * h->units * h->n; }
+static double *uslot(dqmc_handle *h, int i) { return h->su[i]; }
+static double *tslot(dqmc_handle *h, int i) { return h->st[i]; }
+static double *dslot(dqmc_handle *h, int i) { return h->sd[i]; }
+struct Udt { const double *u, *d, *t; };
+static Udt slot_ref(dqmc_handle *h, int i) { return Udt{h->su[i], h->sd[i], h->st[i]}; }
+static void slot_swap_spare(dqmc_handle *h, int i)
+{
+    const int sp = h->K + 1;
+    std::swap(h->su[i], h->su[sp]); std::swap(h->sd[i], h->sd[sp]); std::swap(h->st[i], h->st[sp]);
+}
 
 static int copy_mat(dqmc_handle *h, double *dst, const double *src)
 {
@@ -342,16 +352,23 @@ static int rdivp(dqmc_handle *h, double *A, const double *T)
 }
 
 // ---- calculate_greens_AVX! (stack.jl:337-393) -----------------------------------
-static int calculate_greens(dqmc_handle *h, double *out)
+// L = (Ul, Dl, Tl), R = (Ur, Dr, Tr) are only read (they may be stack slots); h->Ul .. h->Tr are the work matrices
+// the reference overwrites its six inputs with.  L / R may also BE those work matrices (each is consumed before the
+// step that overwrites it).
+static int calculate_greens_src(dqmc_handle *h, double *out, Udt L, Udt R)
 {
     const int n = h->n;
-    GemmArgs g = gemm_base(h, U_(h, h->Tl), 0, U_(h, h->Tr), 1, out);  // :346-348
-    g.colscale = vs_arr(h->Dr, n);
-    g.rowscale = vs_arr(h->Dl, n);
+    GemmArgs g = gemm_base(h, U_(h, L.t), 0, U_(h, R.t), 1, out);  // :346-348
+    g.colscale = vs_arr(R.d, n);
+    g.rowscale = vs_arr(L.d, n);
     CHK(run_gemm(h, g));
     CHK(udt(h, out, h->Tr, h->Dr, nullptr, 0));                        // :349
-    CHK(run_gemm(h, gemm_base(h, U_(h, h->Ul), 0, U_(h, h->Tr), 0, h->Tl)));  // :360
-    CHK(rdivp(h, h->Ur, out));                                         // :361
+    CHK(run_gemm(h, gemm_base(h, U_(h, L.u), 0, U_(h, h->Tr), 0, h->Tl)));    // :360
+    {                                                                  // :361 (out of place: Ur = R.u[:, p] / T)
+        Timed t(h, DQMC_K_TRSM);
+        HIPCHK(launch_trsm_right_upper(h->n, h->units, R.u, h->nn, out, h->nn, h->pivot, nullptr, 0, h->Ur, h->nn,
+                                       h->trsm_w, h->stream, h->trsm_s));
+    }
     g = gemm_base(h, U_(h, h->Tl), 1, U_(h, h->Ur), 0, h->Tr);         // :362 + :368
     g.adddiag = vs_arr(h->Dr, n);
     CHK(run_gemm(h, g));
@@ -363,7 +380,10 @@ static int calculate_greens(dqmc_handle *h, double *out)
     CHK(run_gemm(h, g));
     return 0;
 }
-
+static int calculate_greens(dqmc_handle *h, double *out)
+{
+    return calculate_greens_src(h, out, Udt{h->Ul, h->Dl, h->Tl}, Udt{h->Ur, h->Dr, h->Tr});
+}
 
 // ---- checkerboard products with sparse factors (slice_matrices.jl:104-222, DQMC.jl:731-750) --------------------
 enum { CB_LEFT_B = 0, CB_LEFT_BINV = 1, CB_LEFT_BDAG = 2, CB_RIGHT_B = 3, CB_RIGHT_BINV = 4, CB_RIGHT_ET = 5,
@@ -414,8 +434,10 @@ static int add_slice_sequence_left(dqmc_handle *h, int idx)  // idx 1-based as i
         CHK(run_gemm(h, g));
         X = out;
     }
-    CHK(udt(h, out, uslot(h, idx), dslot(h, idx), h->tmp2, 1));
-    CHK(run_gemm(h, gemm_base(h, U_(h, h->tmp2), 0, U_(h, tslot(h, idx - 1)), 0, tslot(h, idx))));
+    const int sp = h->K + 1;  // new factors into the spare, then slot idx <-> spare: the old slot idx stays readable
+    CHK(udt(h, out, uslot(h, sp), dslot(h, sp), h->tmp2, 1));
+    CHK(run_gemm(h, gemm_base(h, U_(h, h->tmp2), 0, U_(h, tslot(h, idx - 1)), 0, tslot(h, sp))));
+    slot_swap_spare(h, idx);
     return 0;
 }
 static int add_slice_sequence_right(dqmc_handle *h, int idx)
@@ -437,8 +459,10 @@ static int add_slice_sequence_right(dqmc_handle *h, int idx)
         CHK(run_gemm(h, g));
         X = out;
     }
-    CHK(udt(h, out, uslot(h, idx - 1), dslot(h, idx - 1), h->tmp2, 1));
-    CHK(run_gemm(h, gemm_base(h, U_(h, h->tmp2), 0, U_(h, tslot(h, idx)), 0, tslot(h, idx - 1))));
+    const int sp = h->K + 1;
+    CHK(udt(h, out, uslot(h, sp), dslot(h, sp), h->tmp2, 1));
+    CHK(run_gemm(h, gemm_base(h, U_(h, h->tmp2), 0, U_(h, tslot(h, idx)), 0, tslot(h, sp))));
+    slot_swap_spare(h, idx - 1);
     return 0;
 }
 
@@ -471,18 +495,14 @@ static int wrap_greens(dqmc_handle *h, double *gf, int curr_slice, int direction
     return 0;
 }
 
-static int load_slot(dqmc_handle *h, double *U, double *D, double *T, int slot)
-{
-    CHK(copy_mat(h, U, uslot(h, slot)));
-    CHK(copy_vec(h, D, dslot(h, slot)));
-    CHK(copy_mat(h, T, tslot(h, slot)));
-    return 0;
-}
+// identity factors in slot `slot`; the old content stays readable in the spare
 static int reset_slot(dqmc_handle *h, int slot)
 {
-    CHK(set_identity(h, uslot(h, slot)));
-    CHK(set_ones(h, dslot(h, slot)));
-    CHK(set_identity(h, tslot(h, slot)));
+    const int sp = h->K + 1;
+    CHK(set_identity(h, uslot(h, sp)));
+    CHK(set_ones(h, dslot(h, sp)));
+    CHK(set_identity(h, tslot(h, sp)));
+    slot_swap_spare(h, slot);
     return 0;
 }
 static int prop_check(dqmc_handle *h)
@@ -520,22 +540,21 @@ static int propagate(dqmc_handle *h)
         if (h->current_slice % s == 0) {
             h->current_slice += 1;
             if (h->current_slice == 1) {
-                CHK(load_slot(h, h->Ur, h->Dr, h->Tr, 0));
+                const Udt R = slot_ref(h, 0);   // copyto!(s.Ur, s.u_stack[1]) ... (stack.jl:512-520) without the copies
                 CHK(reset_slot(h, 0));
-                CHK(load_slot(h, h->Ul, h->Dl, h->Tl, 0));
-                CHK(calculate_greens(h, h->greens));
+                CHK(calculate_greens_src(h, h->greens, slot_ref(h, 0), R));
             } else if (1 < h->current_slice && h->current_slice <= M) {
                 const int idx = (h->current_slice - 1) / s;
-                CHK(load_slot(h, h->Ur, h->Dr, h->Tr, idx));
+                const Udt R = slot_ref(h, idx);
                 CHK(add_slice_sequence_left(h, idx));
-                CHK(load_slot(h, h->Ul, h->Dl, h->Tl, idx));
+                const Udt L = slot_ref(h, idx);
                 if (h->p.check_propagation_error) {
                     CHK(copy_mat(h, h->greens_temp, h->greens));
                     // stack.jl:534-536 wraps greens_temp unconditionally; its result is only
                     // observable through the check, so the wrap is skipped when the check is off
                     CHK(wrap_greens(h, h->greens_temp, h->current_slice - 1, 1));
                 }
-                CHK(calculate_greens(h, h->greens));
+                CHK(calculate_greens_src(h, h->greens, L, R));
                 if (h->p.check_propagation_error) CHK(prop_check(h));
             } else {
                 CHK(add_slice_sequence_left(h, h->K));
@@ -551,18 +570,17 @@ static int propagate(dqmc_handle *h)
         if ((h->current_slice - 1) % s == 0) {
             h->current_slice -= 1;
             if (h->current_slice == M) {
-                CHK(load_slot(h, h->Ul, h->Dl, h->Tl, h->K));
+                const Udt L = slot_ref(h, h->K);
                 CHK(reset_slot(h, h->K));
-                CHK(load_slot(h, h->Ur, h->Dr, h->Tr, h->K));
-                CHK(calculate_greens(h, h->greens));
+                CHK(calculate_greens_src(h, h->greens, L, slot_ref(h, h->K)));
                 CHK(wrap_greens(h, h->greens, h->current_slice + 1, -1));
             } else if (0 < h->current_slice && h->current_slice < M) {
                 const int idx = h->current_slice / s + 1;
-                CHK(load_slot(h, h->Ul, h->Dl, h->Tl, idx - 1));
+                const Udt L = slot_ref(h, idx - 1);
                 CHK(add_slice_sequence_right(h, idx));
-                CHK(load_slot(h, h->Ur, h->Dr, h->Tr, idx - 1));
+                const Udt R = slot_ref(h, idx - 1);
                 if (h->p.check_propagation_error) CHK(copy_mat(h, h->greens_temp, h->greens));
-                CHK(calculate_greens(h, h->greens));
+                CHK(calculate_greens_src(h, h->greens, L, R));
                 if (h->p.check_propagation_error) CHK(prop_check(h));
                 CHK(wrap_greens(h, h->greens, h->current_slice + 1, -1));
             } else {
@@ -763,9 +781,14 @@ int dqmc_create(const dqmc_params *p, dqmc_handle **out)
         std::vector<int8_t> ones((size_t)h->W * h->N * h->M, 1);
         CHIP(hipMemcpy(h->conf, ones.data(), ones.size(), hipMemcpyHostToDevice));
     }
-    CCHK(dalloc(h, &h->u_stack, (size_t)(h->K + 1) * un));
-    CCHK(dalloc(h, &h->t_stack, (size_t)(h->K + 1) * un));
-    CCHK(dalloc(h, &h->d_stack, (size_t)(h->K + 1) * uv));
+    CCHK(dalloc(h, &h->u_stack, (size_t)(h->K + 2) * un));
+    CCHK(dalloc(h, &h->t_stack, (size_t)(h->K + 2) * un));
+    CCHK(dalloc(h, &h->d_stack, (size_t)(h->K + 2) * uv));
+    for (int i = 0; i <= h->K + 1; ++i) {
+        h->su.push_back(h->u_stack + (size_t)i * un);
+        h->st.push_back(h->t_stack + (size_t)i * un);
+        h->sd.push_back(h->d_stack + (size_t)i * uv);
+    }
     double **mats[] = {&h->Ul, &h->Ur, &h->Tl, &h->Tr, &h->greens, &h->greens_temp, &h->tmp1,
                        &h->tmp2, &h->bufA, &h->bufB, &h->qrV, &h->qrW, &h->qrS};
     for (auto m : mats) CCHK(dalloc(h, m, un));
