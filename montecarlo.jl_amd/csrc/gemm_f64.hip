@@ -341,10 +341,12 @@ hipError_t launch_gemm_flush(int n, int n_units, const double *U, const double *
     const int tm = n / BM, tn = n / BN;
     const int groups = (n_units + 7) / 8;
     const size_t lds = 2 * (size_t)FK * LS * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    static unsigned attr_mask = 0;  // per device (function attributes are per device)
+    if (!(attr_mask & (1u << dev))) {
         (void)hipFuncSetAttribute((const void *)gemm_flush_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
+        attr_mask |= 1u << dev;
     }
     hipExtLaunchKernelGGL(gemm_flush_kernel, dim3(groups * 8 * tm * tn), dim3(256), lds, s, start, stop, 0, n, n_units, U,
                           VT, sUV, C, sC, tm, tn);

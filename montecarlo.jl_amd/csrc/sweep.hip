@@ -304,12 +304,8 @@ hipError_t launch_sweep_chunk(int n, int nb, int n_walkers, int model, double *G
     const bool full = (n % 64 == 0) && (site0 % 64 == 0) && nsites == 64;
 #define SW_LAUNCH3(MT, MD, FL)                                                                                   \
     do {                                                                                                         \
-        static bool attr_set = false;                                                                            \
-        if (!attr_set) {                                                                                         \
-            (void)hipFuncSetAttribute((const void *)sweep_chunk_kernel<MT, MD, FL>,                              \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                   \
-            attr_set = true;                                                                                     \
-        }                                                                                                        \
+        (void)hipFuncSetAttribute((const void *)sweep_chunk_kernel<MT, MD, FL>,                                  \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); /* per device: every launch */ \
         hipLaunchKernelGGL((sweep_chunk_kernel<MT, MD, FL>), grid, block, lds, s, n, nb, model, G, strideG,      \
                            conf_slice, conf_stride, site0, nsites, Uout, VTout, strideUV, sc, rng, stats,        \
                            check_sign);                                                                          \

@@ -363,7 +363,8 @@ class DQMC:
             if m not in known and m != "susceptibilities":
                 raise ValueError("unknown measurement %r" % (m,))
         self.prepare()
-        self.reset_accumulators()
+        if self.last_sweep == 0:  # a resumed run! keeps the measurement state (DQMC.jl:395-411)
+            self.reset_accumulators()
         total = self.p.thermalization + self.p.sweeps
         t0 = time.time()
         for i in range(self.last_sweep + 1, total + 1):

@@ -1,12 +1,9 @@
 #!/bin/bash
-# A/B timing of alternative builds of the library: tools/ab/<name>.so are swapped in turn
-set -e
-cp montecarlo.jl_amd/libdqmc_hip.so /tmp/orig.so
+# A/B timing of alternative builds of the library: tools/ab/<name>.so are selected in turn through DQMC_HIP_LIB
+# (montecarlo.jl_amd/_lib.py); the product library is never touched
 for rep in 1 2; do
 for f in tools/ab/*.so; do
-  cp "$f" montecarlo.jl_amd/libdqmc_hip.so
   echo -n "$(basename $f) : "
-  timeout -k 10 100 python tools/time_sweep_spatial.py | tail -1
+  DQMC_HIP_LIB="$PWD/$f" timeout -k 10 100 python tools/time_sweep_spatial.py | tail -1
 done
 done
-cp /tmp/orig.so montecarlo.jl_amd/libdqmc_hip.so
