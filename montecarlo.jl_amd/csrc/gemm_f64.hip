@@ -28,10 +28,18 @@ constexpr int LS = 80;
 //   element(c, k) = p[c + ld*k]; thread -> k = tid/16, c = (tid%16)*4 .. +3
 // "transposing" tile: k is contiguous in memory.
 //   element(c, k) = p[k + ld*c]; thread -> c = tid/4, k = (tid%4)*4 .. +3
-template <bool KCONTIG>
+// FULL: the tile lies inside the matrix (M, N multiples of 64, K of 16): no predicates at all.  The predicated
+// form compiles to an exec-mask branch cascade per load and to conservative s_waitcnt vmcnt(0) at the merges.
+template <bool KCONTIG, bool FULL>
 __device__ __forceinline__ void tile_load(const double *__restrict__ p, int ld, int c0, int cdim,
                                           int k0, int kdim, int tid, double r[4])
 {
+    if (FULL) {
+        const double *q = KCONTIG ? p + (long)ld * (c0 + (tid >> 2)) + k0 + ((tid & 3) << 2)
+                                  : p + (long)ld * (k0 + (tid >> 4)) + c0 + ((tid & 15) << 2);
+        r[0] = q[0]; r[1] = q[1]; r[2] = q[2]; r[3] = q[3];
+        return;
+    }
     if (!KCONTIG) {
         const int kk = k0 + (tid >> 4), cc = c0 + ((tid & 15) << 2);
         const double *q = p + (long)ld * kk + cc;
@@ -75,7 +83,9 @@ __device__ __forceinline__ void tile_store(double (*Xs)[LS], int tid, const doub
 // an L2 round trip into every k-step.
 #define GEMM_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
-template <bool TA, bool TB>
+// KSM: the k-scaling mode as a compile-time constant (0 none, 2 conf-derived; -1 = read it from the arguments): the
+// per-k-tile mode dispatch, its register copies and its divisions leave the loop for the two common cases
+template <bool TA, bool TB, bool FULL, int KSM>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, int tiles_m, int tiles_n, int gemm_stagger)
 {
     __shared__ double As[2][BK][LS];
@@ -117,13 +127,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, int tiles_m, int 
     constexpr int NKS = TA ? 4 : 1;
     double ksd[2][NKS];
     int ksc[2][NKS];
-    const int ksmode = g.kscale.mode;
+    const int ksmode = KSM >= 0 ? KSM : g.kscale.mode;
     const int kw = unit / g.nb, kblk = unit - kw * g.nb;
 
     auto load = [&](int kt, double (&qa)[4], double (&qb)[4], double (&qd)[NKS], int (&qc)[NKS]) {
         const int k0 = kt * BK;
-        tile_load<TA>(A, g.A.ld, m0, g.M, k0, g.K, tid, qa);
-        tile_load<!TB>(B, g.B.ld, n0, g.N, k0, g.K, tid, qb);
+        tile_load<TA, FULL>(A, g.A.ld, m0, g.M, k0, g.K, tid, qa);
+        tile_load<!TB, FULL>(B, g.B.ld, n0, g.N, k0, g.K, tid, qb);
         if (ksmode != 0) {
             const int kb = TA ? k0 + ((tid & 3) << 2) : k0 + (tid >> 4);
 #pragma unroll
@@ -252,7 +262,16 @@ hipError_t launch_gemm(const GemmArgs &g, hipStream_t s, hipEvent_t start, hipEv
     const int groups = (g.n_units + 7) / 8;
     dim3 grid(groups * 8 * tm * tn), block(256);
     static const int stagger = getenv("DQMC_GEMM_STAGGER") ? atoi(getenv("DQMC_GEMM_STAGGER")) : 0;
-#define GEMM_LAUNCH(TA, TB) hipExtLaunchKernelGGL((gemm_kernel<TA, TB>), grid, block, 0, s, start, stop, 0, g, tm, tn, stagger)
+    const bool full = g.M % BM == 0 && g.N % BN == 0 && g.K % BK == 0;
+#define GEMM_LAUNCH4(TA, TB, FU, KS) \
+    hipExtLaunchKernelGGL((gemm_kernel<TA, TB, FU, KS>), grid, block, 0, s, start, stop, 0, g, tm, tn, stagger)
+#define GEMM_LAUNCH(TA, TB)                                                        \
+    do {                                                                           \
+        if (!full) GEMM_LAUNCH4(TA, TB, false, -1);                                \
+        else if (g.kscale.mode == 0) GEMM_LAUNCH4(TA, TB, true, 0);                \
+        else if (g.kscale.mode == 2) GEMM_LAUNCH4(TA, TB, true, 2);                \
+        else GEMM_LAUNCH4(TA, TB, true, -1);                                       \
+    } while (0)
     if (g.transA) {
         if (g.transB) GEMM_LAUNCH(true, true);
         else GEMM_LAUNCH(true, false);
@@ -261,6 +280,7 @@ hipError_t launch_gemm(const GemmArgs &g, hipStream_t s, hipEvent_t start, hipEv
         else GEMM_LAUNCH(false, false);
     }
 #undef GEMM_LAUNCH
+#undef GEMM_LAUNCH4
     return hipGetLastError();
 }
 
