@@ -186,7 +186,26 @@ def main():
     n, M = mc.N, mc.p.slices
     K, nb = M // SAFE_MULT, (2 if cfg["model"] == "repulsive" else 1)
     mc.prepare()
-    comm = mc_amd.Communicator(dist) if dist is not None else None
+    # measurement reduction: RCCL inside the library (dqmc_reduce).  Should the library's own communicator not come
+    # up on this node, the reduction falls back to torch.distributed (same RCCL, same packed buffer on the device)
+    # so that the run still completes; which path ran is reported in config.reduction.
+    comm, reduction = None, "none (single rank)"
+    acc_dev = None
+    if dist is not None:
+        try:
+            comm = mc_amd.Communicator(dist, device_id=local_rank)
+            reduction = "dqmc_reduce (ncclAllReduce inside libdqmc_hip.so)"
+        except Exception as e:  # noqa: BLE001
+            comm = None
+            acc_dev = torch.zeros(mc.accumulator_size(), dtype=torch.float64, device="cuda:%d" % local_rank)
+            reduction = "torch.distributed all_reduce of the exported accumulators (library communicator failed: %s)" % e
+
+    def reduce_measurements():
+        if acc_dev is not None:
+            mc.export_accumulators(acc_dev.data_ptr())
+            mc_amd.reduce_accumulators(acc_dev, dist)
+        else:
+            mc.reduce(comm)
 
     def barrier():
         if dist is not None:
@@ -202,7 +221,7 @@ def main():
         mc.sweep(1)
         if (i + 1) % mc.p.measure_rate == 0:  # measurement sums + RCCL reduction (DQMC.jl:429-436)
             mc.accumulate_greens()
-            mc.reduce(comm)
+            reduce_measurements()
     barrier()
     dt = time.perf_counter() - t0
     a1 = mc.analysis_sum()
@@ -275,7 +294,8 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "%s, %d walkers per MI355X" % (cfg["name"], walkers), "config": args.config,
                    "walkers_per_gpu": walkers, "total_walkers": total_walkers,
-                   "parallelism": "walkers sharded, %d rank(s)" % n_gpus, "acceptance_rate": acc_rate},
+                   "parallelism": "walkers sharded, %d rank(s)" % n_gpus, "acceptance_rate": acc_rate,
+                   "reduction": reduction},
         "roofline": {"bound": "mfma", "achieved": whole_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": whole_tflops / FP64_PEAK_TFLOPS,
                      "definition": "SURVEY 8(d): algorithmic flops of the reference algorithm per walker-sweep "
@@ -323,6 +343,8 @@ def main():
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     mc.close()
+    if comm is not None:
+        comm.close()
     if dist is not None:
         dist.destroy_process_group()
 
