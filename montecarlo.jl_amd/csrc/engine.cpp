@@ -323,7 +323,9 @@ static int udt(dqmc_handle *h, double *A, double *Uout, double *Dout, double *To
     const double *F = A;  // where the factored matrix ends up (qrW behind the cooperative QR)
     {
         Timed t(h, DQMC_K_QR);
-        HIPCHK(launch_qr_pivot(n, h->units, A, h->nn, h->tau, h->pivot, &h->qr_ws, h->qrW, h->nn, &F, h->stream));
+        // qrV is free until udt_finish writes V: it serves as the hand-over buffer of the two-phase QR
+        HIPCHK(launch_qr_pivot(n, h->units, A, h->nn, h->tau, h->pivot, &h->qr_ws, h->qrW, h->nn, &F, h->stream, h->qrV,
+                               h->nn));
     }
     {
         Timed t(h, DQMC_K_MISC);

@@ -89,8 +89,11 @@ struct QrCoopWorkspace {
 // W (n_units x strideW, may be null): output of the cooperative kernel, which leaves A intact so that a time-out of
 // its hand-offs can be recovered by the single-workgroup kernel launched (guarded) behind it; *factored tells where
 // the factored matrix is (W or A)
+// X (n_units x strideX, may be null): hand-over buffer of the two-phase factorisation at n == 256 (cooperative steps
+// 0..63, then one CU per matrix, qr_tail_kernel); its contents are scratch
 hipError_t launch_qr_pivot(int n, int n_units, double *A, long strideA, double *tau, int *pivot,
-                           QrCoopWorkspace *ws, double *W, long strideW, const double **factored, hipStream_t s);
+                           QrCoopWorkspace *ws, double *W, long strideW, const double **factored, hipStream_t s,
+                           double *X = nullptr, long strideX = 0);
 int qr_coop_blocks_per_cu();
 
 // After launch_qr_pivot: D = |diag R| (UDT.jl:268-272); V = unit-lower Householder

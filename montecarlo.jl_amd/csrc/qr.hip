@@ -508,6 +508,10 @@ __global__ __launch_bounds__(QT_THREADS) void qr_tile256_kernel(int n, int nstep
 // zeroed and epoch >= 1), mailboxes are double buffered by step parity (the skew between
 // workgroups is at most one step, because a step cannot finish without everybody's header).
 // Every spin is bounded; a timeout raises a flag that the host reports.
+// workgroup barrier of the step loop: LDS traffic only is ordered (s_waitcnt lgkmcnt(0)); the packet and output stores
+// of the step stay in flight (__syncthreads() would also wait for vmcnt = 0, i.e. for every store's acknowledgement).
+// Packets validate themselves, so nothing here relies on the order or completion of global stores.
+#define QC_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 constexpr int QC_PARTS = 8;
 constexpr int QC_MB = 264;          // packets (16 B) per mailbox slot: 256 column entries + header
 constexpr unsigned QC_SPIN_LIMIT = 400000u;  // about 0.2 s of polling: far beyond any legitimate co-residency delay
@@ -626,7 +630,8 @@ __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double
                                                      double *__restrict__ tauall, int *__restrict__ pivall,
                                                      double *mailbox,
                                                      unsigned long long epoch, int *fb, int force_sc1,
-                                                     double *__restrict__ Wall, long strideW, int force_timeout)
+                                                     double *__restrict__ Wall, long strideW, int force_timeout,
+                                                     int nsteps, double *__restrict__ Xall, long strideX)
 {
     // my best column, permuted by row group like vperm: row r at (r & 7) * QT_VS + (r >> 3), so that an owner
     // lane (rows rg + 8k) stores pairs of consecutive k with 16-byte writes
@@ -691,7 +696,7 @@ __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double
     for (int q = 1; q < QC_PARTS; ++q) same_xcd = same_xcd && xcc_seen[q] == xcc_seen[0];
     if (force_sc1) same_xcd = false;
 
-    for (int j = 0; j < n; ++j) {
+    for (int j = 0; j < nsteps; ++j) {
         const int par = j & 1;
         const unsigned tag = (unsigned)(epoch * 1024ull + (unsigned long long)j + 1ull);
         // the column now at position j: read here, three barriers before thread 0 rewrites the table
@@ -709,18 +714,23 @@ __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double
                 wc[w][1] = __longlong_as_double((long long)(bp & 0x7fffffffu) | ((long long)(unsigned)bc << 32));
             }
         }
-        __syncthreads();
+        QC_BARRIER();
         double lbn = -1.0;
         int lbp = 0x7fffffff, lbc = -1;
+        {
+            double2 cq[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {  // one 16-byte LDS read per wave candidate
-            const double2 cq = *reinterpret_cast<const double2 *>(wc[q]);
-            const long long pc = __double_as_longlong(cq.y);
-            const int qp = (int)(pc & 0x7fffffff), qc = (int)(pc >> 32);
-            const bool better = cq.x > lbn || (cq.x == lbn && qp < lbp);  // selects, no branches
-            lbn = better ? cq.x : lbn;
-            lbp = better ? qp : lbp;
-            lbc = better ? qc : lbc;
+            for (int q = 0; q < 4; ++q) cq[q] = *reinterpret_cast<const double2 *>(wc[q]);  // four loads in flight
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const long long pc = __double_as_longlong(cq[q].y);
+                const int qp = (int)(pc & 0x7fffffff), qc = (int)(pc >> 32);
+                // bitwise logic: with || and && the compiler builds a chain of scalar branches around each LDS read
+                const bool better = (cq[q].x > lbn) | ((cq[q].x == lbn) & (qp < lbp));
+                lbn = better ? cq[q].x : lbn;
+                lbp = better ? qp : lbp;
+                lbc = better ? qc : lbc;
+            }
         }
         // ---- its owner lanes put the column into LDS
         if (lbc >= 0 && w == ((lbc >> 3) >> 3)) {
@@ -730,7 +740,7 @@ __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double
                 for (int k = 0; k < 32; k += 2) dst[k >> 1] = make_double2(x[k], x[k + 1]);
             }
         }
-        __syncthreads();
+        QC_BARRIER();
         // ---- publish: raw column + header as tagged packets; nothing to wait for
         {
             qc_word *mb = mb_unit + (long)(par * QC_PARTS + part) * QC_MB * 2;
@@ -794,7 +804,7 @@ __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double
                 win[3] = best_xj;
             }
         }
-        __syncthreads();
+        QC_BARRIER();
         double maxval, xi1;
         int jm, cm, wpart;
         {
@@ -838,7 +848,7 @@ __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double
                 if (jm != j) colat[jm] = cj;
             }
         }
-        __syncthreads();
+        QC_BARRIER();
         if (s_abort) break;
         // ---- apply H_j to my column if it is still live (reflectorApply!, UDT.jl:32-50); fresh norm
         if (c < n && mypos > j) {
@@ -862,7 +872,315 @@ __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double
     }
     __syncthreads();
     if (part == 0 && tid < n) piv[tid] = colat[tid];
+    // two-phase form (nsteps < n): the live columns go to X by ORIGINAL column id, all rows (the finished R entries
+    // above row nsteps included); qr_tail_kernel continues from there with the position table just written
+    if (nsteps < n && c < n && mypos >= nsteps) {
+        double *__restrict__ Xc = Xall + (long)unit * strideX + (long)n * c;
+#pragma unroll
+        for (int k = 0; k < 32; ++k)
+            if (rg + 8 * k < n) Xc[rg + 8 * k] = x[k];
+    }
 }
+
+// ---------------------------------------------------------------------------
+// Tail of the factorisation for n == 256.  After QB_J0 cooperative steps the trailing (256 - QB_J0)^2 block fits
+// the registers of ONE CU, and a step there needs no hand-off between workgroups at all: two LDS-only barriers
+// per step instead of two mailbox round trips through L2.  One workgroup of 512 threads per matrix; slot
+// s = (position at hand-over) - QB_J0 lives in thread group g = s % 64 (wave g / 8, lanes 8 (g % 8) .. + 7) as
+// column s / 64 of that group, lane rg holding rows QB_J0 + rg + 8 k.  Pivoting stays logical (slots never move),
+// with the reference's rule: largest norm of the updated trailing column, first in position order
+// (UDT.jl:151-168), swap bookkeeping as UDT.jl:219-231, reflector as UDT.jl:133-148 / :32-50.
+// Rows < QB_J0 of the trailing columns are final when the hand-over happens; they are copied X -> W at the end,
+// when the positions are known.
+// Geometry of a tail kernel that takes over after J0 steps with NW waves: M = 256 - J0 trailing rows and columns,
+// 8 NW thread groups of 8 lanes, CPT = M / (8 NW) columns per group, KR = M / 8 rows per lane.
+//   <128, 4>: 128 x 128 on ONE wave per SIMD (the step is bound by VALU issue: two waves per SIMD halve each other's rate
+//             in the replicated selection / scalar work) - the default;  <64, 8>: 192 x 192 on two waves per SIMD
+template <int J0, int NW>
+struct QbGeo {
+    static constexpr int M = 256 - J0, KR = M / 8, CPT = M / (8 * NW), VS = KR + 2, THREADS = 64 * NW, REGIONS = M / 32;
+    static_assert(M % 32 == 0 && M % (8 * NW) == 0 && KR % 4 == 0, "qr_tail_kernel geometry");
+    static_assert(CPT == 3 || CPT == 4, "qb_step: extraction copies are written out for 3 or 4 columns per group");
+};
+
+#ifdef QB_STAMPS
+__device__ long long *qb_stamp_ptr = nullptr;  // [wave 8][step 192][point 8] of unit 0 (diagnostic build only)
+#define QB_STAMP(P)                                                                                      \
+    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && qb_stamp_ptr)                                      \
+        qb_stamp_ptr[((threadIdx.x >> 6) * 192 + t) * 8 + (P)] = __builtin_amdgcn_s_memtime();
+#else
+#define QB_STAMP(P)
+#endif
+template <int J0, int NW>
+struct QbShared {
+    using G = QbGeo<J0, NW>;
+    // candidate columns of the waves, double-buffered by step parity (a wave is at most one barrier ahead):
+    // row r of wave q's candidate at colbuf[par][q][((r - J0) & 7) * VS + ((r - J0) >> 3)]
+    __attribute__((aligned(16))) double colbuf[2][NW][8 * G::VS];
+    __attribute__((aligned(16))) double wc[2][NW][2];  // per wave: {norm, bits(position | slot << 32)}
+    int posmap[G::M];                                  // (final) position - J0 -> original column
+    int colid[G::M];                                   // slot -> original column
+};
+
+// sqrt(x) and 1/sqrt(x) together (coupled Goldschmidt iterations from v_rsq_f64, then one correction of the root);
+// x > 0 and far from the ends of the exponent range
+__device__ __forceinline__ void qb_sqrt_rsqrt(double x, double &root, double &rroot)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    const double d = __builtin_fma(-g, g, x);
+    root = __builtin_fma(d, h, g);
+    rroot = h + h;
+}
+// 1/x from v_rcp_f64 and two Newton steps (no scaling, no special cases: x is a column norm scale)
+__device__ __forceinline__ double qb_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-x, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+// candidate b replaces a: larger norm, then smaller position (bitwise logic: no branches)
+__device__ __forceinline__ void qb_merge(double &an, int &ap, int &as, double bn, int bp, int bs)
+{
+    const bool better = (bn > an) | ((bn == an) & (bp < ap));
+    an = better ? bn : an;
+    ap = better ? bp : ap;
+    as = better ? bs : as;
+}
+
+// One step, ONE workgroup barrier: every wave extracts its own best live column before the barrier, so that the
+// winner's column is already in LDS when the candidates meet.
+// KB0 = first live block of 8 rows (4 per region of 32 steps)
+template <int J0, int NW, int KB0>
+__device__ __forceinline__ void qb_step(int t, double (&x)[QbGeo<J0, NW>::CPT][QbGeo<J0, NW>::KR],
+                                        double (&nrm)[QbGeo<J0, NW>::CPT], int (&mypos)[QbGeo<J0, NW>::CPT],
+                                        QbShared<J0, NW> &sm, double *__restrict__ Wo, double *__restrict__ tau)
+{
+    using G = QbGeo<J0, NW>;
+    constexpr int CPT = G::CPT, KR = G::KR, VS = G::VS, NG = 8 * NW;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, rg = lane & 7, cg = lane >> 3, g = 8 * w + cg;
+    const int j = J0 + t, par = t & 1;
+    QB_STAMP(0)
+    // ---- best live column of my wave, extracted by its owner lanes
+    {
+        double bn = -1.0;
+        int bp = 0x7fffffff, bs = -1;
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) {
+            const bool better = (mypos[c] >= j) & ((nrm[c] > bn) | ((nrm[c] == bn) & (mypos[c] < bp)));
+            bn = better ? nrm[c] : bn;
+            bp = better ? mypos[c] : bp;
+            bs = better ? g + NG * c : bs;
+        }
+        const double wn = wave_max_f64<8>(bn);
+        const bool eq = (bn == wn) & (bn >= 0.0);
+        unsigned long long m = __ballot(eq);
+        int first = m ? __ffsll((long long)m) - 1 : 0;
+        if ((m >> (first & ~7)) >> 8) {  // equal norms in several columns (wave-uniform, rare): smallest position
+            const unsigned wp = wave_min_u32<8>(eq ? (unsigned)bp : 0xffffffffu);
+            m = __ballot(eq & ((unsigned)bp == wp));
+            first = __ffsll((long long)m) - 1;
+        }
+        const int ws = m ? __builtin_amdgcn_readlane(bs, first) : -1;
+        const int wp = __builtin_amdgcn_readlane(bp, first);
+        QB_STAMP(1)
+        if (ws >= 0 && cg == (ws & 7)) {
+            double2 *dst = reinterpret_cast<double2 *>(sm.colbuf[par][w] + rg * VS);
+            const int oc = ws / NG;
+            // separate copies with static register indices; the distinct asm comments keep the compiler from
+            // merging them into one copy with a run-time column index (which would put x[][] into scratch)
+#define QB_EXTRACT(C)                                                                               \
+    {                                                                                               \
+        asm volatile("; extract column " #C);                                                       \
+        _Pragma("unroll") for (int k = 0; k < KR; k += 2) dst[k >> 1] = make_double2(x[C][k], x[C][k + 1]); \
+        asm volatile("; extracted column " #C);                                                     \
+    }
+            if (oc == 0) QB_EXTRACT(0)
+            else if (oc == 1) QB_EXTRACT(1)
+            else if (CPT == 3 || oc == 2) QB_EXTRACT(2)
+            else QB_EXTRACT(CPT - 1)
+#undef QB_EXTRACT
+        }
+        if (lane == 0) {
+            *reinterpret_cast<double2 *>(sm.wc[par][w]) =
+                make_double2(wn, __longlong_as_double((long long)(unsigned)(wp & 0x7fffffff) | ((long long)(unsigned)ws << 32)));
+        }
+    }
+    QB_STAMP(2)
+    QC_BARRIER();
+    QB_STAMP(3)
+    // ---- the step's pivot among the candidates (all loads first, then a branch-free tree)
+    double maxval;
+    int jm, sp;
+    {
+        double cn[NW];
+        int cp[NW], cs[NW];
+#pragma unroll
+        for (int q = 0; q < NW; ++q) {
+            const double2 cq = *reinterpret_cast<const double2 *>(sm.wc[par][q]);
+            const long long pc = __double_as_longlong(cq.y);
+            cn[q] = cq.x;
+            cp[q] = (int)(pc & 0x7fffffff);
+            cs[q] = (int)(pc >> 32);
+        }
+#pragma unroll
+        for (int st = 1; st < NW; st *= 2) {
+#pragma unroll
+            for (int q = 0; q + st < NW; q += 2 * st) qb_merge(cn[q], cp[q], cs[q], cn[q + st], cp[q + st], cs[q + st]);
+        }
+        maxval = cn[0]; jm = cp[0]; sp = cs[0];
+    }
+    QB_STAMP(4)
+    const bool none = sp < 0;  // nothing live (only with non-finite norms): no reflector, no swap
+    maxval = none ? 0.0 : maxval;
+    jm = none ? j : jm;
+    const double *cb = sm.colbuf[par][none ? 0 : ((sp % NG) >> 3)];
+    const double xj = cb[(t & 7) * VS + (t >> 3)];
+    double2 cvv[KR / 2];
+    {
+        const double2 *vq = reinterpret_cast<const double2 *>(cb + rg * VS);
+#pragma unroll
+        for (int k = KB0; k < KR; k += 2) cvv[k >> 1] = vq[k >> 1];
+    }
+    const double cvo = tid < G::M ? cb[(tid & 7) * VS + (tid >> 3)] : 0.0;
+    // ---- reflector scalars (UDT.jl:133-148; branch-free: a zero column keeps tau = 0 and the column as it is)
+    const bool nz = maxval != 0.0;
+    double rootn, rrootn;
+    qb_sqrt_rsqrt(nz ? maxval : 1.0, rootn, rrootn);
+    const double nu = nz ? copysign(rootn, xj) : 1.0;
+    const double xi = nz ? xj + nu : 1.0;
+    const double tj = nz ? __builtin_fma(fabs(xj), rrootn, 1.0) : 0.0;  // xi / nu
+    const double rcp = qb_rcp(xi);
+    // swap positions j <-> jm (UDT.jl:219-231): every thread tracks its own slots
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+        const int s = g + NG * c;
+        mypos[c] = (s == sp) ? j : ((mypos[c] == j) ? jm : mypos[c]);
+    }
+    if (tid == 0) tau[j] = tj;
+    if (tid < G::M) {  // rows >= J0 of output column j
+        const int r = J0 + tid;
+        Wo[r + 256l * j] = (nz & (r == j)) ? -nu : ((nz & (r > j)) ? cvo * rcp : cvo);
+    }
+    QB_STAMP(5)
+    // ---- H_j on my columns with the unscaled vector u = xi v (u_j = xi), fresh norms of rows > j
+    double u[KR];
+#pragma unroll
+    for (int k = KB0; k < KR; k += 2) {
+        if (k < KB0 + 4) {
+            const int r0 = J0 + rg + 8 * k, r1 = r0 + 8;
+            u[k] = r0 > j ? cvv[k >> 1].x : (r0 == j ? xi : 0.0);
+            u[k + 1] = r1 > j ? cvv[k >> 1].y : (r1 == j ? xi : 0.0);
+        } else {
+            u[k] = cvv[k >> 1].x;
+            u[k + 1] = cvv[k >> 1].y;
+        }
+    }
+    const double trr = tj * rcp;
+    double wv[CPT];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+        double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+        for (int k = KB0; k < KR; k += 2) {
+            d0 = __builtin_fma(u[k], x[c][k], d0);
+            d1 = __builtin_fma(u[k + 1], x[c][k + 1], d1);
+        }
+        wv[c] = d0 + d1;
+    }
+    QB_STAMP(6)
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) wv[c] = (sum8(wv[c]) * rcp) * trr;
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+        double n0 = 0.0, n1 = 0.0;
+#pragma unroll
+        for (int k = KB0; k < KR; k += 2) {
+            const double y0 = __builtin_fma(-u[k], wv[c], x[c][k]), y1 = __builtin_fma(-u[k + 1], wv[c], x[c][k + 1]);
+            x[c][k] = y0;
+            x[c][k + 1] = y1;
+            if (k < KB0 + 4) {
+                n0 += (J0 + rg + 8 * k > j ? 1.0 : 0.0) * (y0 * y0);
+                n1 += (J0 + rg + 8 * (k + 1) > j ? 1.0 : 0.0) * (y1 * y1);
+            } else {
+                n0 = __builtin_fma(y0, y0, n0);
+                n1 = __builtin_fma(y1, y1, n1);
+            }
+        }
+        nrm[c] = n0 + n1;
+    }
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) nrm[c] = sum8(nrm[c]);
+    QB_STAMP(7)
+}
+
+template <int J0, int NW>
+__global__ __launch_bounds__(64 * NW) void qr_tail_kernel(int n_units, const double *__restrict__ Xall, long strideX,
+                                                         double *__restrict__ Wall, long strideW,
+                                                         double *__restrict__ tauall, int *__restrict__ pivall,
+                                                         const int *fb, int epoch_i)
+{
+    using G = QbGeo<J0, NW>;
+    constexpr int CPT = G::CPT, KR = G::KR, NG = 8 * NW;
+    __shared__ QbShared<J0, NW> sm;
+    if (fb[0] == epoch_i) return;  // the cooperative phase timed out: the guarded kernel behind redoes everything
+    const int unit = blockIdx.x;
+    const double *__restrict__ X = Xall + (long)unit * strideX;
+    double *__restrict__ Wo = Wall + (long)unit * strideW;
+    double *__restrict__ tau = tauall + (long)unit * 256;
+    int *__restrict__ piv = pivall + (long)unit * 256;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, rg = lane & 7, cg = lane >> 3, g = 8 * w + cg;
+    if (tid < G::M) sm.colid[tid] = piv[J0 + tid];
+    __syncthreads();
+    double x[CPT][KR], nrm[CPT];
+    int mypos[CPT];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+        const int s = g + NG * c;
+        const double *__restrict__ Xc = X + 256l * sm.colid[s] + J0 + rg;
+        double a = 0.0;
+#pragma unroll
+        for (int k = 0; k < KR; ++k) {
+            x[c][k] = Xc[8 * k];
+            a += x[c][k] * x[c][k];
+        }
+        nrm[c] = sum8(a);
+        mypos[c] = J0 + s;
+    }
+#define QB_REGION(REG)                                                                     \
+    if ((REG) < G::REGIONS)                                                                \
+        for (int t = 32 * (REG); t < 32 * (REG) + 32; ++t)                                 \
+            qb_step<J0, NW, ((REG) < G::REGIONS ? 4 * (REG) : 0)>(t, x, nrm, mypos, sm, Wo, tau);
+    QB_REGION(0) QB_REGION(1) QB_REGION(2) QB_REGION(3) QB_REGION(4) QB_REGION(5)
+#undef QB_REGION
+    static_assert(G::REGIONS <= 6, "qr_tail_kernel: at most six regions");
+    // final pivot vector and the finished rows < J0 of the trailing columns
+    if (rg == 0) {
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) sm.posmap[mypos[c] - J0] = sm.colid[g + NG * c];
+    }
+    __syncthreads();
+    if (tid < G::M) piv[J0 + tid] = sm.posmap[tid];
+    for (int i = tid; i < J0 * G::M; i += G::THREADS) {
+        const int r = i % J0, p = i / J0;
+        Wo[r + 256l * (J0 + p)] = X[r + 256l * sm.posmap[p]];
+    }
+}
+
+#ifdef QB_STAMPS
+extern "C" int dqmc_debug_qb_stamps(void *devptr)
+{
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(qb_stamp_ptr), &devptr, sizeof(void *));
+}
+#endif
 
 // blocks of qr_coop_kernel that one CU holds at a time (occupancy API, capped at the 2 that its registers admit)
 int qr_coop_blocks_per_cu()
@@ -906,7 +1224,7 @@ static hipError_t launch_qr_single(int n, int n_units, double *A, long strideA, 
 
 // *factored: where the factored matrix is (W for the cooperative kernel, which leaves A untouched; else A, in place)
 hipError_t launch_qr_pivot(int n, int n_units, double *A, long strideA, double *tau, int *pivot, QrCoopWorkspace *ws,
-                           double *W, long strideW, const double **factored, hipStream_t s)
+                           double *W, long strideW, const double **factored, hipStream_t s, double *X, long strideX)
 {
     if (n > 1024) return hipErrorInvalidValue;
     *factored = A;
@@ -921,10 +1239,26 @@ hipError_t launch_qr_pivot(int n, int n_units, double *A, long strideA, double *
             ws->epoch += 1;
             static const int force_sc1 = getenv("DQMC_QR_SC1") != nullptr;  // write-through packets regardless of placement
             static const int force_to = getenv("DQMC_QR_FORCE_TIMEOUT") != nullptr;
+            // n == 256: the first steps cooperatively, the rest on one CU per matrix (qr_tail_kernel)
+            static const char *tail_env = getenv("DQMC_QR_TAIL");  // "0": none, "64": 192 x 192 tail, default 128 x 128
+            static const int tail_j0 = tail_env ? atoi(tail_env) : 128;
+            const bool two_phase = n == 256 && X && (tail_j0 == 64 || tail_j0 == 128);
             hipLaunchKernelGGL(qr_coop_kernel, dim3(blocks), dim3(256), 0, s, n, n_units, A, strideA, tau, pivot,
-                               ws->mailbox, ws->epoch, ws->fb, force_sc1, W, strideW, force_to);
+                               ws->mailbox, ws->epoch, ws->fb, force_sc1, W, strideW, force_to, two_phase ? tail_j0 : n, X,
+                               strideX);
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) return e;
+            if (two_phase) {
+                const int ep = (int)(ws->epoch & 0x7fffffffull);
+                if (tail_j0 == 64)
+                    hipLaunchKernelGGL((qr_tail_kernel<64, 8>), dim3(n_units), dim3(512), 0, s, n_units, X, strideX, W, strideW,
+                                       tau, pivot, ws->fb, ep);
+                else
+                    hipLaunchKernelGGL((qr_tail_kernel<128, 4>), dim3(n_units), dim3(256), 0, s, n_units, X, strideX, W, strideW,
+                                       tau, pivot, ws->fb, ep);
+                e = hipGetLastError();
+                if (e != hipSuccess) return e;
+            }
             *factored = W;
             return launch_qr_single(n, n_units, W, strideW, tau, pivot, A, strideA, ws->fb,
                                     (int)(ws->epoch & 0x7fffffffull), s);
