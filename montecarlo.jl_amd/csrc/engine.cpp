@@ -38,6 +38,8 @@ struct dqmc_handle {
     hipStream_t stream = nullptr;
     // constants (nb x n x n)
     double *eT = nullptr, *eTinv = nullptr, *eT2 = nullptr, *eTinv2 = nullptr;
+    double *eT2T = nullptr;  // transposed copy of eT2: A operand of the daggered slice products in slab.hip
+    bool slab = false;       // n == 256 dense path: slice chains and wraps as slab-resident launches
     int8_t *conf = nullptr;  // W x (N x M)
     // stack (slot-major): u/t: (K+1) x units x n^2 ; d: (K+1) x units x n
     double *u_stack = nullptr, *t_stack = nullptr, *d_stack = nullptr;
@@ -417,12 +419,55 @@ static int cb_mult(dqmc_handle *h, int which, int slice, const double *X, double
     return timing_push(h, ea, eb, DQMC_K_GEMM);
 }
 
+// ---- slab-resident product chains (slab.hip) -----------------------------------------
+static SlabArgs slab_base(dqmc_handle *h, const double *X0, long x_su, long x_sb, double *out)
+{
+    SlabArgs a{};
+    a.n_units = h->units; a.nb = h->nb; a.nsteps = 0;
+    a.X0 = X0; a.x_su = x_su; a.x_sb = x_sb;
+    a.out = out; a.out_su = h->nn;
+    a.conf_stride = (long)h->N * h->M;
+    a.epl = h->epl; a.eml = h->eml;
+    return a;
+}
+static const int8_t *conf_slice(dqmc_handle *h, int slice) { return h->conf + (long)(slice - 1) * h->N; }
+static void slab_step_const(dqmc_handle *h, SlabArgs &a, const double *C)  // shared constant, per block
+{
+    SlabStep &st = a.st[a.nsteps++];
+    st = SlabStep{};
+    st.A = C; st.su = 0; st.sb = h->nn;
+}
+static void slab_step_unit(dqmc_handle *h, SlabArgs &a, const double *A)
+{
+    SlabStep &st = a.st[a.nsteps++];
+    st = SlabStep{};
+    st.A = A; st.su = h->nn; st.sb = 0;
+}
+static int run_slab(dqmc_handle *h, const SlabArgs &a)
+{
+    hipEvent_t ea, eb;
+    timing_events(h, &ea, &eb);
+    HIPCHK(launch_slab_chain(a, h->stream, ea, eb));
+    return timing_push(h, ea, eb, DQMC_K_GEMM);
+}
+
 // ---- slice sequences (stack.jl:272-311, slice_matrices.jl:42-76) -------------------
 static int add_slice_sequence_left(dqmc_handle *h, int idx)  // idx 1-based as in the reference
 {
     const double *X = uslot(h, idx - 1);
     double *out = nullptr;
-    for (int t = 0; t < h->s; ++t) {
+    if (h->slab && !h->cb.on && h->s <= SLAB_MAX_STEPS) {  // the s products B_l X in one launch
+        out = h->bufA;
+        SlabArgs a = slab_base(h, X, h->nn, 0, out);
+        for (int t = 0; t < h->s; ++t) {
+            slab_step_const(h, a, h->eT2);
+            a.st[t].pre_conf = conf_slice(h, (idx - 1) * h->s + 1 + t);
+            a.st[t].pre_sign = +1;
+        }
+        a.col_d = dslot(h, idx - 1); a.col_stride = h->n;  // stack.jl:281
+        CHK(run_slab(h, a));
+    }
+    else for (int t = 0; t < h->s; ++t) {
         const int slice = (idx - 1) * h->s + 1 + t;
         out = (t & 1) ? h->bufB : h->bufA;
         if (h->cb.on) {
@@ -446,7 +491,18 @@ static int add_slice_sequence_right(dqmc_handle *h, int idx)
 {
     const double *X = uslot(h, idx);
     double *out = nullptr;
-    for (int t = 0; t < h->s; ++t) {
+    if (h->slab && !h->cb.on && h->s <= SLAB_MAX_STEPS) {  // the s products B_l' X = eV (eT2' X) in one launch
+        out = h->bufA;
+        SlabArgs a = slab_base(h, X, h->nn, 0, out);
+        for (int t = 0; t < h->s; ++t) {
+            slab_step_const(h, a, h->eT2T);
+            a.st[t].post_conf = conf_slice(h, idx * h->s - t);
+            a.st[t].post_sign = +1;
+        }
+        a.col_d = dslot(h, idx); a.col_stride = h->n;  // stack.jl:305
+        CHK(run_slab(h, a));
+    }
+    else for (int t = 0; t < h->s; ++t) {
         const int slice = idx * h->s - t;
         out = (t & 1) ? h->bufB : h->bufA;
         if (h->cb.on) {
@@ -468,8 +524,39 @@ static int add_slice_sequence_right(dqmc_handle *h, int idx)
     return 0;
 }
 
-// wrap_greens! (stack.jl:491-500)
-static int wrap_greens(dqmc_handle *h, double *gf, int curr_slice, int direction)
+// wrap_greens! (stack.jl:491-500), out of place, one launch: column slab c of the result is
+//   +1:  eT2 (eV (G (eV^-1 eTinv2[:, c])))          -1:  eV^-1 (eTinv2 (G eT2[:, c])) eV[c]
+static int wrap_greens_slab(dqmc_handle *h, const double *src, double *dst, int curr_slice, int direction)
+{
+    if (direction == -1) {
+        const int8_t *c = conf_slice(h, curr_slice - 1);
+        SlabArgs a = slab_base(h, h->eT2, 0, h->nn, dst);
+        slab_step_unit(h, a, src);
+        slab_step_const(h, a, h->eTinv2);
+        a.st[1].post_conf = c; a.st[1].post_sign = -1;
+        a.col_conf = c; a.col_sign = +1;
+        return run_slab(h, a);
+    }
+    const int8_t *c = conf_slice(h, curr_slice);
+    SlabArgs a = slab_base(h, h->eTinv2, 0, h->nn, dst);
+    slab_step_unit(h, a, src);
+    a.st[0].pre_conf = c; a.st[0].pre_sign = -1;
+    slab_step_const(h, a, h->eT2);
+    a.st[1].pre_conf = c; a.st[1].pre_sign = +1;
+    return run_slab(h, a);
+}
+static int wrap_greens_inplace(dqmc_handle *h, double *gf, int curr_slice, int direction);
+// *gf <- wrapped *gf (the slab path writes into tmp1 and exchanges the two pointers)
+static int wrap_greens(dqmc_handle *h, double **gf, int curr_slice, int direction)
+{
+    if (h->slab && !h->cb.on) {
+        CHK(wrap_greens_slab(h, *gf, h->tmp1, curr_slice, direction));
+        std::swap(*gf, h->tmp1);
+        return 0;
+    }
+    return wrap_greens_inplace(h, *gf, curr_slice, direction);
+}
+static int wrap_greens_inplace(dqmc_handle *h, double *gf, int curr_slice, int direction)
 {
     if (h->cb.on) {  // both products in place, slab by slab
         const int l = direction == -1 ? curr_slice - 1 : curr_slice;
@@ -551,10 +638,14 @@ static int propagate(dqmc_handle *h)
                 CHK(add_slice_sequence_left(h, idx));
                 const Udt L = slot_ref(h, idx);
                 if (h->p.check_propagation_error) {
-                    CHK(copy_mat(h, h->greens_temp, h->greens));
                     // stack.jl:534-536 wraps greens_temp unconditionally; its result is only
                     // observable through the check, so the wrap is skipped when the check is off
-                    CHK(wrap_greens(h, h->greens_temp, h->current_slice - 1, 1));
+                    if (h->slab && !h->cb.on) {
+                        CHK(wrap_greens_slab(h, h->greens, h->greens_temp, h->current_slice - 1, 1));
+                    } else {
+                        CHK(copy_mat(h, h->greens_temp, h->greens));
+                        CHK(wrap_greens(h, &h->greens_temp, h->current_slice - 1, 1));
+                    }
                 }
                 CHK(calculate_greens_src(h, h->greens, L, R));
                 if (h->p.check_propagation_error) CHK(prop_check(h));
@@ -565,7 +656,7 @@ static int propagate(dqmc_handle *h)
                 CHK(propagate(h));
             }
         } else {
-            CHK(wrap_greens(h, h->greens, h->current_slice, 1));
+            CHK(wrap_greens(h, &h->greens, h->current_slice, 1));
             h->current_slice += 1;
         }
     } else {
@@ -575,7 +666,7 @@ static int propagate(dqmc_handle *h)
                 const Udt L = slot_ref(h, h->K);
                 CHK(reset_slot(h, h->K));
                 CHK(calculate_greens_src(h, h->greens, L, slot_ref(h, h->K)));
-                CHK(wrap_greens(h, h->greens, h->current_slice + 1, -1));
+                CHK(wrap_greens(h, &h->greens, h->current_slice + 1, -1));
             } else if (0 < h->current_slice && h->current_slice < M) {
                 const int idx = h->current_slice / s + 1;
                 const Udt L = slot_ref(h, idx - 1);
@@ -584,7 +675,7 @@ static int propagate(dqmc_handle *h)
                 if (h->p.check_propagation_error) CHK(copy_mat(h, h->greens_temp, h->greens));
                 CHK(calculate_greens_src(h, h->greens, L, R));
                 if (h->p.check_propagation_error) CHK(prop_check(h));
-                CHK(wrap_greens(h, h->greens, h->current_slice + 1, -1));
+                CHK(wrap_greens(h, &h->greens, h->current_slice + 1, -1));
             } else {
                 CHK(add_slice_sequence_right(h, 1));
                 h->direction = 1;
@@ -592,7 +683,7 @@ static int propagate(dqmc_handle *h)
                 CHK(propagate(h));
             }
         } else {
-            CHK(wrap_greens(h, h->greens, h->current_slice, -1));
+            CHK(wrap_greens(h, &h->greens, h->current_slice, -1));
             h->current_slice -= 1;
         }
     }
@@ -778,6 +869,15 @@ int dqmc_create(const dqmc_params *p, dqmc_handle **out)
     CHIP(hipMemcpy(h->eTinv, p->eTinv, cn * sizeof(double), hipMemcpyHostToDevice));
     CHIP(hipMemcpy(h->eT2, p->eT2, cn * sizeof(double), hipMemcpyHostToDevice));
     CHIP(hipMemcpy(h->eTinv2, p->eTinv2, cn * sizeof(double), hipMemcpyHostToDevice));
+    if (h->n == 256 && !getenv("DQMC_NO_SLAB")) {
+        std::vector<double> tr(cn);
+        for (int b = 0; b < nb; ++b)
+            for (int j = 0; j < h->n; ++j)
+                for (int i = 0; i < h->n; ++i) tr[(size_t)b * h->nn + j + (size_t)h->n * i] = p->eT2[(size_t)b * h->nn + i + (size_t)h->n * j];
+        CCHK(dalloc(h, &h->eT2T, cn));
+        CHIP(hipMemcpy(h->eT2T, tr.data(), cn * sizeof(double), hipMemcpyHostToDevice));
+        h->slab = true;
+    }
     CCHK(dalloc(h, &h->conf, (size_t)h->W * h->N * h->M));
     {
         std::vector<int8_t> ones((size_t)h->W * h->N * h->M, 1);
@@ -1132,7 +1232,7 @@ int dqmc_wrap_greens(dqmc_handle *h, int32_t slice, int32_t direction)
     if (direction != 1 && direction != -1) return fail(h, DQMC_ERR_INVALID, "direction must be +1 or -1");
     const int l = direction == 1 ? slice : slice - 1;
     if (l < 1 || l > h->M) return fail(h, DQMC_ERR_INVALID, "wrap_greens: slice out of range");
-    CHK(wrap_greens(h, h->greens, slice, direction));
+    CHK(wrap_greens(h, &h->greens, slice, direction));
     return dqmc_synchronize(h);
 }
 

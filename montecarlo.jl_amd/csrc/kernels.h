@@ -67,6 +67,26 @@ struct GemmArgs {
 // start/stop (optional): events that take the dispatch's own begin/end timestamps (hipExtLaunchKernelGGL),
 // i.e. the kernel-only duration a profiler's kernel trace reports
 hipError_t launch_gemm(const GemmArgs &g, hipStream_t s, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
+// Chain of left products on a column slab kept in LDS (slab.hip; n = 256 only, ld = 256):
+//   X_s = post_s (.) (A_s (pre_s (.) X_{s-1})), out = X_nsteps (.) colscale;  pre/post = exp(sign lambda conf[row]) or none
+constexpr int SLAB_MAX_STEPS = 10;
+struct SlabStep {
+    const double *A; long su, sb;        // A_s at A + unit su + block sb (su = 0: shared constant)
+    const int8_t *pre_conf; int pre_sign;    // conf pointers already offset to the slice; null = no scaling
+    const int8_t *post_conf; int post_sign;
+};
+struct SlabArgs {
+    int n_units, nb, nsteps;
+    SlabStep st[SLAB_MAX_STEPS];
+    const double *X0; long x_su, x_sb;   // X_0 (per unit, or a shared constant with x_su = 0)
+    double *out; long out_su;            // must not alias X0 or any per-unit A_s
+    const double *col_d; long col_stride;  // final column scaling by an array (per unit), or
+    const int8_t *col_conf; int col_sign;  // by exp(sign lambda conf[col]), or none
+    long conf_stride;                    // per walker
+    double epl, eml;
+};
+hipError_t launch_slab_chain(const SlabArgs &a, hipStream_t s, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
+
 // C += U V' for the delayed-update flush: U[t + n m], VT[t + n m], m < 64 slots; n % 64 == 0
 hipError_t launch_gemm_flush(int n, int n_units, const double *U, const double *VT, long sUV, double *C, long sC,
                              hipStream_t s, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);

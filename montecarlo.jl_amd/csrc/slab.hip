@@ -1,0 +1,188 @@
+// slab.hip — chains of left products with the column slab resident in LDS (n = 256).
+//
+//   X_s = post_s (.) ( A_s * ( pre_s (.) X_{s-1} ) ),  s = 1 .. nsteps,    out = X_nsteps (.) colscale
+//
+// for the sequences of slice-matrix products that the sweep runs back to back on one matrix:
+//   * add_slice_sequence_left/right (stack.jl:272-311): s = safe_mult products B_l X or B_l' X
+//     (slice_matrices.jl:42-48, 70-76) -- one launch instead of ten GEMM launches;
+//   * wrap_greens! (stack.jl:491-500): G <- B G B^-1 = eT2 (eV (G (eV^-1 eTinv2))) evaluated column slab by column slab
+//     (X_0 = a slab of the CONSTANT eTinv2, A_1 = G, A_2 = eT2) -- one launch instead of two.
+//
+// One workgroup (4 waves) owns a 256 x 32 column slab of X: 8 workgroups per unit, 256 workgroups for 32 units, mapped
+// so that the 8 slabs of a unit sit on one XCD (they stream the same A through that XCD's L2).  The slab lives in LDS
+// (two buffers of 32 x 258 doubles: a step reads one and writes the other, ONE LDS-only barrier per step); A_s is
+// never staged: no two waves of a workgroup share an A element (wave w owns rows 64 w .. 64 w + 63 of the product), so
+// every lane loads its MFMA A operand straight from L2 into registers, four k-pairs ahead, also across the step
+// boundary.  v_mfma_f64_16x16x4_f64, 4 x 2 tiles per wave; the k index of the two MFMAs of a pair is interleaved
+// (k = 8 p + 2 g and 8 p + 2 g + 1) so that one ds_read_b128 feeds two MFMAs, and the tile rows are permuted
+// (tile row 4 r + g <-> matrix row 4 g + r) so that a lane's four accumulator registers are four consecutive rows:
+// slab write-back and the final store are 32-byte pieces, the final store covers whole 128-byte lines.
+// Scalings (exp(+-lambda conf), HubbardModelAttractive.jl:100-110 / HubbardModelRepulsive.jl:113-126) are applied to
+// the accumulators at write-back: post_s and pre_{s+1} together, once per element.
+#include "kernels.h"
+#include <hip/hip_ext.h>
+
+namespace dqmc {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+#define SLAB_MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+#define SLAB_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+constexpr int SL_N = 256;
+constexpr int SL_W = 32;     // slab width
+constexpr int SL_LD = 258;   // LDS column stride (doubles): 16 lanes x 16 B of one read pass hit 64 distinct banks
+constexpr int SL_RING = 4;   // A operands in flight: pairs p .. p + 3
+
+// exp(sign lambda conf) of row i (block b): vs_conf() of engine.cpp
+__device__ __forceinline__ double slab_conf_val(const int8_t *conf, int i, int sign, int blk, double epl, double eml)
+{
+    const bool plus = (conf[i] > 0) == (sign > 0);
+    return (plus != (blk != 0)) ? epl : eml;
+}
+
+__global__ __launch_bounds__(256) void slab_chain_kernel(SlabArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double slab_lds[];
+    const int bid = blockIdx.x, xcd = bid & 7, seq = bid >> 3;
+    const int unit = (seq >> 3) * 8 + xcd, slab = seq & 7;
+    if (unit >= a.n_units) return;
+    const int wk = unit / a.nb, blk = unit - wk * a.nb;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, ci = lane & 15;
+    double *buf0 = slab_lds, *buf1 = slab_lds + SL_W * SL_LD;
+    const long conf_off = (long)wk * a.conf_stride;
+
+    // ---- X_0 slab -> LDS, scaled by pre_1
+    {
+        const double *X0 = a.X0 + (long)unit * a.x_su + (long)blk * a.x_sb + (long)SL_N * (SL_W * slab);
+        const int col = tid >> 3, r0 = 32 * (tid & 7);
+        const int8_t *pc = a.st[0].pre_conf ? a.st[0].pre_conf + conf_off : nullptr;
+#pragma unroll
+        for (int i = 0; i < 32; i += 2) {
+            double2 v = *reinterpret_cast<const double2 *>(X0 + (long)SL_N * col + r0 + i);
+            if (pc) {
+                v.x *= slab_conf_val(pc, r0 + i, a.st[0].pre_sign, blk, a.epl, a.eml);
+                v.y *= slab_conf_val(pc, r0 + i + 1, a.st[0].pre_sign, blk, a.epl, a.eml);
+            }
+            *reinterpret_cast<double2 *>(buf0 + col * SL_LD + r0 + i) = v;
+        }
+    }
+    // my A rows: tile row ci <-> matrix row 4 (ci & 3) + (ci >> 2) of each 16-row tile; k = 8 p + 2 g (+ 1)
+    const int arow = 64 * w + 4 * (ci & 3) + (ci >> 2);
+    auto a_ptr = [&](int s) {
+        return a.st[s].A + (long)unit * a.st[s].su + (long)blk * a.st[s].sb + arow + (long)SL_N * (2 * g);
+    };
+    double areg[SL_RING][4][2];  // [ring slot][row tile][k of the pair]
+    const int total = 32 * a.nsteps;
+    const double *ap = a_ptr(0);
+    int q_issue = 0;  // next pair to load (global pair counter over all steps)
+    auto issue = [&](int slot) {
+        if (q_issue < total) {
+            if ((q_issue & 31) == 0) ap = a_ptr(q_issue >> 5);
+            const double *p = ap + (long)SL_N * 8 * (q_issue & 31);
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {
+                areg[slot][rt][0] = p[16 * rt];
+                areg[slot][rt][1] = p[16 * rt + SL_N];
+            }
+        }
+        ++q_issue;
+    };
+#pragma unroll
+    for (int i = 0; i < SL_RING - 1; ++i) issue(i);
+    __syncthreads();
+
+    d4 acc[4][2];
+    for (int s = 0; s < a.nsteps; ++s) {
+        const double *src = (s & 1) ? buf1 : buf0;
+        double *dst = (s & 1) ? buf0 : buf1;
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = (d4){0.0, 0.0, 0.0, 0.0};
+        const double *bp = src + ci * SL_LD + 2 * g;  // + 16 ct SL_LD + 8 p
+        double2 breg[2][2];                            // [parity of p][ct]
+        breg[0][0] = *reinterpret_cast<const double2 *>(bp);
+        breg[0][1] = *reinterpret_cast<const double2 *>(bp + 16 * SL_LD);
+        for (int p0 = 0; p0 < 32; p0 += SL_RING) {
+#pragma unroll
+            for (int i = 0; i < SL_RING; ++i) {
+                const int p = p0 + i;
+                issue((i + SL_RING - 1) % SL_RING);
+                if (p + 1 < 32) {
+                    breg[(i + 1) & 1][0] = *reinterpret_cast<const double2 *>(bp + 8 * (p + 1));
+                    breg[(i + 1) & 1][1] = *reinterpret_cast<const double2 *>(bp + 16 * SL_LD + 8 * (p + 1));
+                }
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt) {
+                    acc[rt][0] = SLAB_MFMA(areg[i][rt][0], breg[i & 1][0].x, acc[rt][0]);
+                    acc[rt][1] = SLAB_MFMA(areg[i][rt][0], breg[i & 1][1].x, acc[rt][1]);
+                }
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt) {
+                    acc[rt][0] = SLAB_MFMA(areg[i][rt][1], breg[i & 1][0].y, acc[rt][0]);
+                    acc[rt][1] = SLAB_MFMA(areg[i][rt][1], breg[i & 1][1].y, acc[rt][1]);
+                }
+            }
+        }
+        // ---- write-back: rows 64 w + 16 rt + 4 g + r (r = 0..3), column 16 ct + ci; scale post_s (.) pre_{s+1}
+        const bool last = s + 1 == a.nsteps;
+        const int8_t *c_post = a.st[s].post_conf ? a.st[s].post_conf + conf_off : nullptr;
+        const int8_t *c_pre = (!last && a.st[s + 1].pre_conf) ? a.st[s + 1].pre_conf + conf_off : nullptr;
+        const int s_post = a.st[s].post_sign, s_pre = last ? 0 : a.st[s + 1].pre_sign;
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+            const int row = 64 * w + 16 * rt + 4 * g;
+            double f[4] = {1.0, 1.0, 1.0, 1.0};
+            if (c_post) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) f[r] = slab_conf_val(c_post, row + r, s_post, blk, a.epl, a.eml);
+            }
+            if (c_pre) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) f[r] *= slab_conf_val(c_pre, row + r, s_pre, blk, a.epl, a.eml);
+            }
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                const int col = 16 * ct + ci;
+                double v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = acc[rt][ct][r] * f[r];
+                if (!last) {
+                    double *d = dst + col * SL_LD + row;
+                    *reinterpret_cast<double2 *>(d) = make_double2(v[0], v[1]);
+                    *reinterpret_cast<double2 *>(d + 2) = make_double2(v[2], v[3]);
+                } else {
+                    const int gc = SL_W * slab + col;  // global column
+                    double cs = 1.0;
+                    if (a.col_d) cs = a.col_d[(long)unit * a.col_stride + gc];
+                    else if (a.col_conf) cs = slab_conf_val(a.col_conf + conf_off, gc, a.col_sign, blk, a.epl, a.eml);
+                    double *o = a.out + (long)unit * a.out_su + (long)SL_N * gc + row;
+                    *reinterpret_cast<double2 *>(o) = make_double2(v[0] * cs, v[1] * cs);
+                    *reinterpret_cast<double2 *>(o + 2) = make_double2(v[2] * cs, v[3] * cs);
+                }
+            }
+        }
+        if (!last) SLAB_BARRIER();
+    }
+}
+
+hipError_t launch_slab_chain(const SlabArgs &a, hipStream_t s, hipEvent_t start, hipEvent_t stop)
+{
+    if (a.nsteps < 1 || a.nsteps > SLAB_MAX_STEPS) return hipErrorInvalidValue;
+    const size_t lds = 2 * SL_W * SL_LD * sizeof(double);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    static unsigned attr_mask = 0;  // per device
+    if (!(attr_mask & (1u << dev))) {
+        hipError_t e = hipFuncSetAttribute((const void *)slab_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_mask |= 1u << dev;
+    }
+    const int groups = (a.n_units + 7) / 8;
+    const dim3 grid(groups * 64), block(256);
+    if (start) hipExtLaunchKernelGGL(slab_chain_kernel, grid, block, lds, s, start, stop, 0, a);
+    else hipLaunchKernelGGL(slab_chain_kernel, grid, block, lds, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace dqmc
