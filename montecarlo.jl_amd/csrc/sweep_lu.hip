@@ -353,6 +353,7 @@ __device__ __noinline__ void lu4_wave(int n, const double *__restrict__ Gall, lo
             }
     }
     if (PRO) {
+        LU4_STAMP(400 + 8 * J + 0);
         // LDS scratch aliased onto the (not yet used) step ring: R0 block [64 t'][66] and the T' tiles of waves 0..2
         double *Rl = reinterpret_cast<double *>(&sm.aST[0][0][0]);
         double *ttx = Rl + 64 * 66;
@@ -392,6 +393,11 @@ __device__ __noinline__ void lu4_wave(int n, const double *__restrict__ Gall, lo
                     xr[Jb][q] = imgp[LU_IMG + 16 * Jb + 4 * q + g];
                 }
             d4 xz[4], tt[4];
+#ifdef LU4_STAMPS
+            LU4_STAMP(400 + 8 * J + 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            LU4_STAMP(400 + 8 * J + 2);
+#endif
 #pragma unroll
             for (int Jb = 0; Jb < 4; ++Jb) {
 #pragma unroll
@@ -418,6 +424,7 @@ __device__ __noinline__ void lu4_wave(int n, const double *__restrict__ Gall, lo
                 for (int q = 0; q < 4; ++q) o = MFMA(opQ[Jb][q], a[q], o);
                 tt[Jb] = o;
             }
+            LU4_STAMP(400 + 8 * J + 3);
             if (J < 3) {
 #pragma unroll
                 for (int K = 0; K < 4; ++K)
@@ -425,6 +432,7 @@ __device__ __noinline__ void lu4_wave(int n, const double *__restrict__ Gall, lo
                     for (int q = 0; q < 4; ++q) ttx[((J * 4 + K) * 4 + q) * 64 + lane] = tt[K][q];
             }
             __syncthreads();  // R0 block and the T' tiles of the other waves are in LDS
+            LU4_STAMP(400 + 8 * J + 4);
 #pragma unroll
             for (int I = 0; I <= J; ++I)
 #pragma unroll
@@ -793,7 +801,9 @@ hipError_t launch_sweep_lu(int n, int nb, int n_walkers, const double *G, long s
 constexpr int FL_LDR = 66;  // row stride of the R0 tile in LDS (doubles): ci * 66 + g hits 32 distinct 8-byte slots
 // NT = number of 16-wide column tiles per wave: the workgroup covers 64 rows x 16 NT columns (the triangular solves
 // of a row tile are repeated by every workgroup of that row, so wider is cheaper: NT = 8 when n % 128 == 0).
-template <bool FULL, int NT>
+// NCP = column passes of one workgroup (it then covers 64 rows x 16 NT NCP columns with ONE pair of triangular solves):
+// used by the fused launch, where fewer, longer flush workgroups leave CUs for the elimination workgroups
+template <bool FULL, int NT, int NCP = 1>
 __device__ __forceinline__ void flush_lu_body(int bid, int n, int n_units, const double *__restrict__ Gin_all,
                                               double *__restrict__ Gout_all, long strideG, int site0, int nsites,
                                               const double *__restrict__ img_all, int tiles_m, int tiles_n)
@@ -807,7 +817,8 @@ __device__ __forceinline__ void flush_lu_body(int bid, int n, int n_units, const
     const int unit = (seq / T) * 8 + xcd;
     if (unit >= n_units) return;
     const int tile = seq % T;
-    const int m0 = (tile % tiles_m) * 64, n0 = (tile / tiles_m) * (16 * NT);
+    const int m0 = (tile % tiles_m) * 64, n00 = (tile / tiles_m) * (16 * NT * NCP);
+    int n0 = n00;
     const double *__restrict__ Gin = Gin_all + (long)unit * strideG;
     double *__restrict__ Gout = Gout_all + (long)unit * strideG;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, ci = lane & 15;
@@ -889,23 +900,50 @@ __device__ __forceinline__ void flush_lu_body(int bid, int n, int n_units, const
         for (int q = 0; q < 4; ++q) o = MFMA(img[LU_OFF_Q + J * LU_TILE + q * 64 + lane], a[q], o);
         tt[J] = o;
     }
-    // G tile += T R0
-#pragma unroll
-    for (int K = 0; K < 4; ++K)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int sk = 16 * K + 4 * q + g;
+    for (int cp = 0; cp < NCP; ++cp) {
+        if (cp > 0) {  // next 16 NT columns: G tile and R0 tile again (the solves are done)
+            n0 = n00 + cp * 16 * NT;
 #pragma unroll
             for (int jt = 0; jt < NT; ++jt)
-                acc[jt] = MFMA(Rl[(16 * jt + ci) * FL_LDR + sk], tt[K][q], acc[jt]);
-        }
 #pragma unroll
-    for (int jt = 0; jt < NT; ++jt)
+                for (int r = 0; r < 4; ++r) {
+                    const int tp = n0 + 16 * jt + 4 * r + g;
+                    acc[jt][r] = Gin[tq + (long)n * (FULL ? tp : min(tp, n - 1))];
+                }
+            __syncthreads();  // everybody is done with the previous R0 tile
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int tp = n0 + 16 * jt + 4 * r + g;
-            if (FULL || (t < n && tp < n)) Gout[t + (long)n * tp] = acc[jt][r];
+            for (int pass = 0; pass < NT / 4; ++pass) {
+                const int tl = pass * 64 + (tid >> 2), tp = n0 + tl, s0 = (tid & 3) * 16;
+                double *d = Rl + tl * FL_LDR + s0;
+                if (FULL) {
+                    const double2 *q = reinterpret_cast<const double2 *>(Gin + (long)n * tp + site0 + s0);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) reinterpret_cast<double2 *>(d)[i] = q[i];
+                } else {
+                    for (int i = 0; i < 16; ++i)
+                        d[i] = (tp < n && s0 + i < nsites) ? Gin[(long)n * tp + site0 + s0 + i] : 0.0;
+                }
+            }
+            __syncthreads();
         }
+        // G tile += T R0
+#pragma unroll
+        for (int K = 0; K < 4; ++K)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int sk = 16 * K + 4 * q + g;
+#pragma unroll
+                for (int jt = 0; jt < NT; ++jt)
+                    acc[jt] = MFMA(Rl[(16 * jt + ci) * FL_LDR + sk], tt[K][q], acc[jt]);
+            }
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int tp = n0 + 16 * jt + 4 * r + g;
+                if (FULL || (t < n && tp < n)) Gout[t + (long)n * tp] = acc[jt][r];
+            }
+    }
 }
 
 template <bool FULL, int NT>
@@ -936,15 +974,15 @@ struct SweepFusedArgs {
     int *errflag;
     int tiles_m, tiles_n;
 };
-template <int NB, int NT>
+template <int NB, int NT, int NCP>
 __global__ __launch_bounds__(256) void sweep_fused_kernel(SweepFusedArgs a)
 {
     if ((int)blockIdx.x < a.n_walkers)
         lu4_block<NB, true, true>(blockIdx.x, a.n, a.Gin, a.strideG, a.conf_slice, a.conf_stride, a.site0, 64, a.img, a.sc,
                                   a.rngs, a.stats, a.check_sign, a.errflag, a.site0p, a.imgp);
     else
-        flush_lu_body<true, NT>((int)blockIdx.x - a.n_walkers, a.n, a.n_units, a.Gin, a.Gout, a.strideG, a.site0p, 64,
-                                a.imgp, a.tiles_m, a.tiles_n);
+        flush_lu_body<true, NT, NCP>((int)blockIdx.x - a.n_walkers, a.n, a.n_units, a.Gin, a.Gout, a.strideG, a.site0p, 64,
+                                     a.imgp, a.tiles_m, a.tiles_n);
 }
 
 hipError_t launch_sweep_flush_lu(int n, int n_units, const double *Gin, double *Gout, long strideG, int site0,
@@ -990,7 +1028,9 @@ hipError_t launch_sweep_fused(int n, int nb, int n_walkers, const double *Gin, d
     a.n = n; a.n_walkers = n_walkers; a.n_units = n_units; a.Gin = Gin; a.Gout = Gout; a.strideG = strideG;
     a.conf_slice = conf_slice; a.conf_stride = conf_stride; a.site0 = site0; a.site0p = site0p; a.img = img; a.imgp = imgp;
     a.sc = sc; a.rngs = rng; a.stats = stats; a.check_sign = check_sign; a.errflag = errflag;
-    a.tiles_m = n / 64; a.tiles_n = n / (16 * nt);
+    // two column passes per flush workgroup when that makes the whole launch co-resident (one workgroup per CU)
+    const int ncp = (wide && n % 256 == 0) ? 2 : 1;
+    a.tiles_m = n / 64; a.tiles_n = n / (16 * nt * ncp);
     const int groups = (n_units + 7) / 8;
     const int flush_blocks = groups * 8 * a.tiles_m * a.tiles_n;
     const size_t lds_flush = ((size_t)LU_STRIDE + 16 * nt * FL_LDR) * sizeof(double);
@@ -1000,16 +1040,18 @@ hipError_t launch_sweep_fused(int n, int nb, int n_walkers, const double *Gin, d
     (void)hipGetDevice(&dev);
     static unsigned attr_mask = 0;
     if (!(attr_mask & (1u << dev))) {
-        (void)hipFuncSetAttribute((const void *)sweep_fused_kernel<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void *)sweep_fused_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void *)sweep_fused_kernel<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void *)sweep_fused_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)sweep_fused_kernel<1, 8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)sweep_fused_kernel<1, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)sweep_fused_kernel<1, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)sweep_fused_kernel<2, 8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)sweep_fused_kernel<2, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)sweep_fused_kernel<2, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_mask |= 1u << dev;
     }
     dim3 grid(n_walkers + flush_blocks), block(256);
-#define FU_LAUNCH(NBV, NTV) hipExtLaunchKernelGGL((sweep_fused_kernel<NBV, NTV>), grid, block, lds, s, start, stop, 0, a)
-    if (nb == 1) { if (wide) FU_LAUNCH(1, 8); else FU_LAUNCH(1, 4); }
-    else { if (wide) FU_LAUNCH(2, 8); else FU_LAUNCH(2, 4); }
+#define FU_LAUNCH(NBV, NTV, NCPV) hipExtLaunchKernelGGL((sweep_fused_kernel<NBV, NTV, NCPV>), grid, block, lds, s, start, stop, 0, a)
+    if (nb == 1) { if (ncp == 2) FU_LAUNCH(1, 8, 2); else if (wide) FU_LAUNCH(1, 8, 1); else FU_LAUNCH(1, 4, 1); }
+    else { if (ncp == 2) FU_LAUNCH(2, 8, 2); else if (wide) FU_LAUNCH(2, 8, 1); else FU_LAUNCH(2, 4, 1); }
 #undef FU_LAUNCH
     return hipGetLastError();
 }

@@ -25,6 +25,10 @@ for rep in range(3):
     for J in range(4):
         b = 320 + 8 * J
         print(" wave %d: prologue done %d, start %d, tiles loaded %d, block ends %s, done %d" % (J, rel(t[b + 7]) if t[b + 7] else 0, rel(t[b]), rel(t[b + 1]), [int(rel(x)) if x else 0 for x in t[b + 2:b + 6]], rel(t[b + 6])))
+    if t[400]:
+        for J in range(4):
+            b = 400 + 8 * J
+            print(" wave %d prologue: entered %d, loads issued %d, loads arrived %d, solves done %d, barrier passed %d" % ((J,) + tuple(int(rel(t[b + k])) for k in range(5))))
     print(" pivot step stamps (rel):", [int(rel(x)) for x in piv[::4]])
     d = np.diff(piv)
     print(" pivot step deltas: block0 %s" % d[:15].tolist())
