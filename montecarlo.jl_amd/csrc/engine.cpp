@@ -830,7 +830,17 @@ int dqmc_create(const dqmc_params *p, dqmc_handle **out)
     // chunk to its own 64 x 64 block; the flush workgroups take two column passes each, so that at 32 units the whole
     // launch is co-resident, one workgroup per CU): 36 us per chunk against 24 + 17 for the two separate launches.
     // DQMC_SWEEP_SPLIT selects the separate launches.
-    h->sweep_fused = getenv("DQMC_SWEEP_SPLIT") == nullptr;
+    // With more units than that the phase is throughput-bound and the separate launches win (config 4 on one GPU,
+    // 512 units: 688 vs 715 ms per sweep), so the fused form is used only when its grid fits the CUs.
+    h->sweep_fused = false;
+    if (getenv("DQMC_SWEEP_SPLIT") == nullptr && h->n % 64 == 0) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, p->device_id) == hipSuccess) {
+            const int ncp = (h->n % 256 == 0) ? 2 : 1, nt = (h->n % 128 == 0) ? 8 : 4;
+            const int flush_blocks = ((h->units + 7) / 8) * 8 * (h->n / 64) * (h->n / (16 * nt * ncp));
+            h->sweep_fused = h->W + flush_blocks <= prop.multiProcessorCount;
+        }
+    }
     // lambda = acosh(exp(U*dtau/2)) (Attractive.jl:103,118; Repulsive.jl:116,138)
     h->lambda = std::acosh(std::exp(0.5 * p->U * p->delta_tau));
     h->epl = std::exp(h->lambda);

@@ -1122,8 +1122,103 @@ __device__ __forceinline__ void qb_step(int t, double (&x)[QbGeo<J0, NW>::CPT][Q
     QB_STAMP(7)
 }
 
+// ---- the last 64 steps on ONE wave, one column per lane (qr_tail_kernel<128, 4> hands over at j = 192) -----------
+// Lane l holds rows 192..255 of the column that sits at position 192 + l at the hand-over: a reflector is applied with
+// no cross-lane reduction at all, the pivot search is one wave-wide DPP reduction, and the pivot column reaches the
+// other lanes as LDS broadcast reads - no workgroup barrier, no second wave.  Pivoting stays logical.
+constexpr int QF_LD = 65;
+struct QfShared {
+    double Mx[64 * QF_LD];                         // hand-over: row r - 192 of the column at position 192 + p at [r][p]
+    __attribute__((aligned(16))) double ub[64];    // the step's reflector (unscaled, u_j = xi), rows 192..255
+    int cidp[64];                                  // original column at position 192 + p (hand-over order)
+};
+// R8: steps t = 8 R8 .. 8 R8 + 7 (relative to 192); rows below 8 R8 are finished in every live column
+template <int R8>
+__device__ __forceinline__ void qf_step(int t, double (&x)[64], double &nrm, int &mypos, double &s_nu, double &s_rcp,
+                                        double &s_tau, int &s_nz, QfShared &fs)
+{
+    constexpr int R0 = 8 * R8, NR = 64 - R0;
+    const int lane = threadIdx.x & 63, j = 192 + t;
+    // ---- pivot: largest norm among the live columns, then smallest position (UDT.jl:151-168)
+    const double bn = (mypos >= j) ? nrm : -1.0;
+    const double wn = wave_max_f64<1>(bn);
+    const bool eq = (bn == wn) & (bn >= 0.0);
+    unsigned long long m = __ballot(eq);
+    if (__popcll(m) > 1) {
+        const unsigned wp = wave_min_u32<1>(eq ? (unsigned)mypos : 0xffffffffu);
+        m = __ballot(eq & ((unsigned)mypos == wp));
+    }
+    double maxval = wn;
+    if (m == 0) {  // nothing live (non-finite norms only): the column at position j, no reflector
+        m = __ballot(mypos == j);
+        maxval = 0.0;
+    }
+    const int pl = __ffsll((long long)m) - 1;
+    const int jm = __builtin_amdgcn_readlane(mypos, pl);
+    // element j of every lane's own column, then the pivot lane's one as a wave-uniform value
+    double xown = x[R0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) xown = (t - R0 == i) ? x[R0 + i] : xown;
+    const double xj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xown), pl),
+                                       __builtin_amdgcn_readlane(__double2loint(xown), pl));
+    // ---- reflector scalars (UDT.jl:133-148)
+    const bool nz = maxval != 0.0;
+    double rootn, rrootn;
+    qb_sqrt_rsqrt(nz ? maxval : 1.0, rootn, rrootn);
+    const double nu = nz ? copysign(rootn, xj) : 1.0;
+    const double xi = nz ? xj + nu : 1.0;
+    const double tj = nz ? __builtin_fma(fabs(xj), rrootn, 1.0) : 0.0;
+    const double rcp = qb_rcp(xi);
+    const double trr = tj * rcp;
+    // ---- the pivot lane publishes u (rows <= j masked, u_j = xi) and keeps what its output column needs
+    if (lane == pl) {
+        double2 *ub2 = reinterpret_cast<double2 *>(fs.ub + R0);
+#pragma unroll
+        for (int i = 0; i < NR; i += 2) {
+            double a = x[R0 + i], b = x[R0 + i + 1];
+            if (i < 8) {
+                a = (R0 + i > t) ? a : ((R0 + i == t) ? xi : 0.0);
+                b = (R0 + i + 1 > t) ? b : ((R0 + i + 1 == t) ? xi : 0.0);
+            }
+            ub2[i >> 1] = make_double2(a, b);
+        }
+        s_nu = nu; s_rcp = rcp; s_tau = tj; s_nz = nz ? 1 : 0;
+    }
+    // swap positions j <-> jm (UDT.jl:219-231)
+    mypos = (lane == pl) ? j : ((mypos == j) ? jm : mypos);
+    // ---- H_j on the live columns (one per lane): dot, update, fresh norm of rows > j; two passes over u in LDS
+    if (mypos > j) {
+        const double2 *ub2 = reinterpret_cast<const double2 *>(fs.ub + R0);
+        double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < NR; i += 2) {
+            const double2 uu = ub2[i >> 1];
+            d0 = __builtin_fma(uu.x, x[R0 + i], d0);
+            d1 = __builtin_fma(uu.y, x[R0 + i + 1], d1);
+        }
+        const double wv = ((d0 + d1) * rcp) * trr;
+        asm volatile("" ::: "memory");  // second pass re-reads u from LDS instead of keeping 64 doubles in registers
+        double n0 = 0.0, n1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < NR; i += 2) {
+            const double2 uu = ub2[i >> 1];
+            const double y0 = __builtin_fma(-uu.x, wv, x[R0 + i]), y1 = __builtin_fma(-uu.y, wv, x[R0 + i + 1]);
+            x[R0 + i] = y0;
+            x[R0 + i + 1] = y1;
+            if (i < 8) {
+                n0 += (R0 + i > t ? 1.0 : 0.0) * (y0 * y0);
+                n1 += (R0 + i + 1 > t ? 1.0 : 0.0) * (y1 * y1);
+            } else {
+                n0 = __builtin_fma(y0, y0, n0);
+                n1 = __builtin_fma(y1, y1, n1);
+            }
+        }
+        nrm = n0 + n1;
+    }
+}
+
 template <int J0, int NW>
-__global__ __launch_bounds__(64 * NW) void qr_tail_kernel(int n_units, const double *__restrict__ Xall, long strideX,
+__global__ __launch_bounds__(64 * NW) void qr_tail_kernel(int n_units, double *__restrict__ Xall, long strideX,
                                                          double *__restrict__ Wall, long strideW,
                                                          double *__restrict__ tauall, int *__restrict__ pivall,
                                                          const int *fb, int epoch_i)
@@ -1133,7 +1228,7 @@ __global__ __launch_bounds__(64 * NW) void qr_tail_kernel(int n_units, const dou
     __shared__ QbShared<J0, NW> sm;
     if (fb[0] == epoch_i) return;  // the cooperative phase timed out: the guarded kernel behind redoes everything
     const int unit = blockIdx.x;
-    const double *__restrict__ X = Xall + (long)unit * strideX;
+    double *__restrict__ X = Xall + (long)unit * strideX;
     double *__restrict__ Wo = Wall + (long)unit * strideW;
     double *__restrict__ tau = tauall + (long)unit * 256;
     int *__restrict__ piv = pivall + (long)unit * 256;
@@ -1155,13 +1250,74 @@ __global__ __launch_bounds__(64 * NW) void qr_tail_kernel(int n_units, const dou
         nrm[c] = sum8(a);
         mypos[c] = J0 + s;
     }
+    // FIN: the last 64 steps run on wave 0 alone, one column per lane (qf_step)
+    constexpr bool FIN = (J0 == 128 && NW == 4);
+    constexpr int NREG = FIN ? G::REGIONS - 2 : G::REGIONS;
 #define QB_REGION(REG)                                                                     \
-    if ((REG) < G::REGIONS)                                                                \
+    if ((REG) < NREG)                                                                      \
         for (int t = 32 * (REG); t < 32 * (REG) + 32; ++t)                                 \
             qb_step<J0, NW, ((REG) < G::REGIONS ? 4 * (REG) : 0)>(t, x, nrm, mypos, sm, Wo, tau);
     QB_REGION(0) QB_REGION(1) QB_REGION(2) QB_REGION(3) QB_REGION(4) QB_REGION(5)
 #undef QB_REGION
     static_assert(G::REGIONS <= 6, "qr_tail_kernel: at most six regions");
+    if (FIN) {
+        __shared__ QfShared fs;
+        constexpr int KH = (192 - J0) / 8;  // row blocks below row 192
+        // hand-over: rows >= 192 of the live columns to LDS by position, their finished rows J0..191 to X
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) {
+            if (mypos[c] >= 192) {
+                const int p = mypos[c] - 192, cid = sm.colid[g + NG * c];
+#pragma unroll
+                for (int k = KH; k < KR; ++k) fs.Mx[(rg + 8 * (k - KH)) * QF_LD + p] = x[c][k];
+#pragma unroll
+                for (int k = 0; k < KH; ++k) X[256l * cid + J0 + rg + 8 * k] = x[c][k];
+                if (rg == 0) fs.cidp[p] = cid;
+            } else if (rg == 0) {
+                sm.posmap[mypos[c] - J0] = sm.colid[g + NG * c];
+            }
+        }
+        __syncthreads();
+        if (w == 0) {
+            double xc[64];
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int r = 0; r < 64; r += 2) {
+                xc[r] = fs.Mx[r * QF_LD + lane];
+                xc[r + 1] = fs.Mx[(r + 1) * QF_LD + lane];
+                a0 = __builtin_fma(xc[r], xc[r], a0);
+                a1 = __builtin_fma(xc[r + 1], xc[r + 1], a1);
+            }
+            double cn = a0 + a1, s_nu = 1.0, s_rcp = 1.0, s_tau = 0.0;
+            int cpos = 192 + lane, s_nz = 0;
+            const int cid = fs.cidp[lane];
+#define QF_REGION(R) \
+    for (int t = 8 * (R); t < 8 * (R) + 8; ++t) qf_step<(R)>(t, xc, cn, cpos, s_nu, s_rcp, s_tau, s_nz, fs);
+            QF_REGION(0) QF_REGION(1) QF_REGION(2) QF_REGION(3) QF_REGION(4) QF_REGION(5) QF_REGION(6) QF_REGION(7)
+#undef QF_REGION
+            // every lane was the pivot exactly once: its column goes to its final position
+            double *__restrict__ Wc = Wo + 256l * cpos + 192;
+#pragma unroll
+            for (int r = 0; r < 64; ++r) {
+                const int R = 192 + r;
+                Wc[r] = (R < cpos || !s_nz) ? xc[r] : ((R == cpos) ? -s_nu : xc[r] * s_rcp);
+            }
+            tau[cpos] = s_tau;
+            sm.posmap[cpos - J0] = cid;
+        }
+        __syncthreads();
+        if (tid < G::M) piv[J0 + tid] = sm.posmap[tid];
+        // finished rows of the trailing columns: rows < J0 of all of them, rows J0..191 of the last 64
+        for (int i = tid; i < J0 * G::M; i += G::THREADS) {
+            const int r = i % J0, p = i / J0;
+            Wo[r + 256l * (J0 + p)] = X[r + 256l * sm.posmap[p]];
+        }
+        for (int i = tid; i < (192 - J0) * 64; i += G::THREADS) {
+            const int r = J0 + i % (192 - J0), p = 192 - J0 + i / (192 - J0);
+            Wo[r + 256l * (J0 + p)] = X[r + 256l * sm.posmap[p]];
+        }
+        return;
+    }
     // final pivot vector and the finished rows < J0 of the trailing columns
     if (rg == 0) {
 #pragma unroll

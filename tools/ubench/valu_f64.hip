@@ -30,6 +30,20 @@ __global__ __launch_bounds__(1024) void k(int iters, double *sink, long long *ou
             for (int i = 0; i < 8; ++i) m[i] = (m[i] + 3) ^ it;
 #pragma unroll
             for (int i = 0; i < 8; ++i) m[i] = (m[i] + 5) ^ it;
+        } else if (MODE == 4) {  // 16 DEPENDENT f64 fma
+#pragma unroll
+            for (int i = 0; i < 16; ++i) a[0] = __builtin_fma(a[0], x, y);
+        } else if (MODE == 5) {  // 16 dependent v_cndmask pairs (select chain on f64)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) a[0] = (m[0] == it + i) ? a[1] : a[0] + 0.0 * a[2];
+        } else if (MODE == 6) {  // 8 dependent (dpp pair + f64 max): one wave-reduction level each
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int lo = __double2loint(a[0]), hi = __double2hiint(a[0]);
+                const double o = __hiloint2double(__builtin_amdgcn_update_dpp(hi, hi, 0x118, 0xf, 0xf, false),
+                                                  __builtin_amdgcn_update_dpp(lo, lo, 0x118, 0xf, 0xf, false));
+                a[0] = fmax(a[0], o) + y;
+            }
         } else {  // 16 f64 mul (not fma)
 #pragma unroll
             for (int i = 0; i < 16; ++i) a[i] = a[i] * x;
@@ -54,13 +68,16 @@ int main()
     hipMalloc(&sink, 1024 * 8);
     hipMalloc(&out, 16 * 8);
     const int iters = 2000;
-    const char *names[4] = {"16 indep f64 fma", "8 f64 fma + 8x(int mul, xor)", "16x(int add, xor)", "16 indep f64 mul"};
-    for (int mode = 0; mode < 4; ++mode)
-        for (int threads = 256; threads <= 1024; threads *= 2) {
+    const char *names[7] = {"16 indep f64 fma", "8 f64 fma + 8x(int mul, xor)", "16x(int add, xor)", "16 indep f64 mul", "16 dependent f64 fma", "16 dependent f64 selects(+add)", "8 dependent dpp+max+add levels"};
+    for (int mode = 0; mode < 7; ++mode)
+        for (int threads = 256; threads <= 512; threads *= 2) {
             for (int rep = 0; rep < 2; ++rep) {
                 if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(1), dim3(threads), 0, 0, iters, sink, out);
                 if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(1), dim3(threads), 0, 0, iters, sink, out);
                 if (mode == 2) hipLaunchKernelGGL(k<2>, dim3(1), dim3(threads), 0, 0, iters, sink, out);
+                if (mode == 4) hipLaunchKernelGGL(k<4>, dim3(1), dim3(threads), 0, 0, iters, sink, out);
+                if (mode == 5) hipLaunchKernelGGL(k<5>, dim3(1), dim3(threads), 0, 0, iters, sink, out);
+                if (mode == 6) hipLaunchKernelGGL(k<6>, dim3(1), dim3(threads), 0, 0, iters, sink, out);
                 if (mode == 3) hipLaunchKernelGGL(k<3>, dim3(1), dim3(threads), 0, 0, iters, sink, out);
                 hipDeviceSynchronize();
             }
