@@ -250,12 +250,16 @@ def main():
     whole_tflops = F["total"] * value / n_gpus / 1e12  # per GPU
     bounds = {"gemm": "mfma", "flush": "mfma", "qr": "latency", "trsm": "latency", "sweep": "latency", "misc": "hbm"}
     notes = {
-        "gemm": "gemm_kernel<TA,TB>: slice-matrix products, wraps, the GEMMs of calculate_greens and of compact-WY Q",
-        "flush": "sweep_flush_lu_kernel: the accepted rank-1 updates of 64 sites as block-triangular solves + a K=64 "
-                 "update of G (MFMA); HBM side 16 n^2 B per unit and launch",
-        "qr": "pivoted Householder QR (n sequential column steps per factorisation)",
+        "gemm": "slab_chain_kernel (the safe_mult slice products of a stack interval in one launch, wrap_greens in one "
+                "launch) + gemm_kernel<TA,TB> (the GEMMs of calculate_greens and of compact-WY Q)",
+        "flush": "sweep_flush_lu_kernel, last chunk of a slice only (the other chunks are applied inside the fused "
+                 "sweep launches): block-triangular solves + a K=64 update of G (MFMA); HBM side 16 n^2 B per unit "
+                 "and launch",
+        "qr": "pivoted Householder QR (n sequential column steps per factorisation): qr_coop_kernel (steps 0..127, "
+              "8 workgroups per matrix) + qr_tail_kernel (steps 128..255 on one CU per matrix)",
         "trsm": "rdivp! and the compact-WY triangle (blocked substitution, MFMA)",
-        "sweep": "sweep_lu4_kernel: Metropolis decisions = conditional elimination of G[c,c] (sequential site chain)",
+        "sweep": "sweep_lu4_kernel / sweep_fused_kernel: Metropolis decisions = conditional elimination of G[c,c] "
+                 "(sequential site chain), fused with the flush of the previous chunk when the grid is co-resident",
         "misc": "udt_finish, copies, propagation-error check",
     }
     kernels = []
@@ -301,7 +305,8 @@ def main():
                      "definition": "SURVEY 8(d): algorithmic flops of the reference algorithm per walker-sweep "
                                    "(%.3f GFLOP at the measured acceptance) x walker-sweeps/s per GPU" % (F["total"] / 1e9),
                      "traffic": traffic,
-                     "traffic_note": "HBM bytes of one full 256^3 x 32 gemm_kernel launch, profiles/*_pmc_gemm.json",
+                     "traffic_note": "HBM bytes (PMC FETCH_SIZE + WRITE_SIZE, guide corrections) of one launch of the most "
+                                     "frequent MFMA kernel, see profiles/*_pmc_gemm.json (kernel, algorithmic bytes)",
                      "kernels": kernels, "kernel_ms_sum": sum_ms, "kernel_pass_ms_per_step": kp_ms,
                      "kernel_pass_note": "family times from HIP events attached to the launches of a second region of "
                                          "the same K steps; ms_per_step / value come from the event-free region",

@@ -300,6 +300,7 @@ static int alloc_qr_workspace(dqmc_handle *h)
     // co-residency: what the occupancy API reports for the kernel on this device (its ~200 VGPRs admit 2 per CU)
     h->qr_ws.max_blocks = prop.multiProcessorCount * qr_coop_blocks_per_cu();
     h->qr_ws.epoch = 0;
+    if (const char *e = getenv("DQMC_QR_TAIL")) h->qr_ws.tail_j0 = atoi(e);  // A/B switch, read per handle
     return 0;
 }
 static int check_qr_workspace(dqmc_handle *h)

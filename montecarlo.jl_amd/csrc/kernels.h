@@ -104,6 +104,7 @@ struct QrCoopWorkspace {
     int *fb = nullptr;    // [0] launch epoch of the last cooperative launch that timed out, [1] fallbacks taken
     unsigned long long epoch = 0;
     int max_blocks = 0;   // launch the cooperative kernel only if its grid fits (co-residency)
+    int tail_j0 = 128;    // n == 256: hand-over step to qr_tail_kernel (0 = cooperative kernel only; 64, 96, 128)
 };
 // ws may be null: single-workgroup kernels only
 // W (n_units x strideW, may be null): output of the cooperative kernel, which leaves A intact so that a time-out of

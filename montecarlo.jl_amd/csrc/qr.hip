@@ -1251,7 +1251,7 @@ __global__ __launch_bounds__(64 * NW) void qr_tail_kernel(int n_units, double *_
         mypos[c] = J0 + s;
     }
     // FIN: the last 64 steps run on wave 0 alone, one column per lane (qf_step)
-    constexpr bool FIN = (J0 == 128 && NW == 4);
+    constexpr bool FIN = (J0 >= 96 && NW <= 5);
     constexpr int NREG = FIN ? G::REGIONS - 2 : G::REGIONS;
 #define QB_REGION(REG)                                                                     \
     if ((REG) < NREG)                                                                      \
@@ -1396,9 +1396,8 @@ hipError_t launch_qr_pivot(int n, int n_units, double *A, long strideA, double *
             static const int force_sc1 = getenv("DQMC_QR_SC1") != nullptr;  // write-through packets regardless of placement
             static const int force_to = getenv("DQMC_QR_FORCE_TIMEOUT") != nullptr;
             // n == 256: the first steps cooperatively, the rest on one CU per matrix (qr_tail_kernel)
-            static const char *tail_env = getenv("DQMC_QR_TAIL");  // "0": none, "64": 192 x 192 tail, default 128 x 128
-            static const int tail_j0 = tail_env ? atoi(tail_env) : 128;
-            const bool two_phase = n == 256 && X && (tail_j0 == 64 || tail_j0 == 128);
+            const int tail_j0 = ws->tail_j0;  // DQMC_QR_TAIL at handle creation; default 128 x 128 tail
+            const bool two_phase = n == 256 && X && (tail_j0 == 64 || tail_j0 == 96 || tail_j0 == 128);
             hipLaunchKernelGGL(qr_coop_kernel, dim3(blocks), dim3(256), 0, s, n, n_units, A, strideA, tau, pivot,
                                ws->mailbox, ws->epoch, ws->fb, force_sc1, W, strideW, force_to, two_phase ? tail_j0 : n, X,
                                strideX);
@@ -1408,6 +1407,9 @@ hipError_t launch_qr_pivot(int n, int n_units, double *A, long strideA, double *
                 const int ep = (int)(ws->epoch & 0x7fffffffull);
                 if (tail_j0 == 64)
                     hipLaunchKernelGGL((qr_tail_kernel<64, 8>), dim3(n_units), dim3(512), 0, s, n_units, X, strideX, W, strideW,
+                                       tau, pivot, ws->fb, ep);
+                else if (tail_j0 == 96)
+                    hipLaunchKernelGGL((qr_tail_kernel<96, 5>), dim3(n_units), dim3(320), 0, s, n_units, X, strideX, W, strideW,
                                        tau, pivot, ws->fb, ep);
                 else
                     hipLaunchKernelGGL((qr_tail_kernel<128, 4>), dim3(n_units), dim3(256), 0, s, n_units, X, strideX, W, strideW,

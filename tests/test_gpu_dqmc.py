@@ -235,3 +235,33 @@ def test_cooperative_qr_timeout_falls_back(gpu, O):
     p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "fallbacks" in p.stdout
+
+
+@pytest.mark.parametrize("switch", ["DQMC_NO_SLAB", "DQMC_SWEEP_SPLIT", "DQMC_QR_TAIL"])
+def test_fast_paths_against_their_plain_forms(gpu, switch):
+    """The round-2 launch forms at n = 256 (slab-resident product chains, elimination fused with the previous chunk's
+    flush, two-phase QR) against the forms they replace, selected per handle through the environment: same seeds,
+    HS field identical, G within the parity tolerance (the forms differ by reassociation only)."""
+    def run(env):
+        old = os.environ.get(switch)
+        if env is None:
+            os.environ.pop(switch, None)
+        else:
+            os.environ[switch] = env
+        try:
+            mc = gpu.DQMC(gpu.HubbardModelAttractive(16, 2), beta=2.0, n_walkers=2, seed=7)
+            mc.prepare()
+            mc.sweep(2)
+            out = [mc.conf(w).copy() for w in range(2)], [mc.greens_eff(w)[0].copy() for w in range(2)]
+            mc.close()
+            return out
+        finally:
+            if old is None:
+                os.environ.pop(switch, None)
+            else:
+                os.environ[switch] = old
+    conf_fast, g_fast = run(None)
+    conf_plain, g_plain = run("0" if switch == "DQMC_QR_TAIL" else "1")
+    for w in range(2):
+        assert np.array_equal(conf_fast[w], conf_plain[w])
+        assert relerr(g_fast[w], g_plain[w]) < TOL

@@ -59,6 +59,34 @@ def test_udt_contracts(gpu, O, n, apply_pivot):
             assert relerr(U[i], Uo) < 1e-9
 
 
+def test_two_phase_qr_against_cooperative_alone(gpu):
+    """n = 256: 128 cooperative steps + qr_tail_kernel (one CU per matrix, last 64 steps one column per lane)
+    against the cooperative kernel factoring everything (DQMC_QR_TAIL=0): same pivots, same factors up to rounding"""
+    import os
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((8, 256, 256))
+    X[1] *= np.exp(rng.uniform(-20, 20, size=256))[None, :]
+    X[2][:, 7] = 0.0                      # a zero column (tau = 0 branch)
+    X[3][:, 9] = X[3][:, 200]             # equal norms: the tie goes to the smaller position
+    U1, D1, T1, p1 = gpu.udt_AVX_pivot(X, False)
+    os.environ["DQMC_QR_TAIL"] = "0"
+    try:
+        U0, D0, T0, p0 = gpu.udt_AVX_pivot(X, False)
+    finally:
+        del os.environ["DQMC_QR_TAIL"]
+    for i in range(X.shape[0]):
+        assert sorted(p1[i]) == list(range(1, 257))
+        if i == 2:  # singular input: D[255] = 0 and T = D^-1 R is not finite (as in the reference); the zero column
+            assert p1[i][255] == 8 and D1[i][255] == 0.0  # must come out last, with tau = 0 and nothing hanging
+            continue
+        P = np.zeros((256, 256)); P[np.arange(256), p1[i] - 1] = 1
+        rec = (U1[i] * D1[i]) @ np.triu(T1[i]) @ P
+        scale = np.abs(X[i]).max(axis=0)
+        assert (np.abs(rec - X[i]) / scale[None, :]).max() < 1e-12
+        assert np.array_equal(p0[i], p1[i])
+        assert relerr(D1[i], D0[i]) < 1e-12
+
+
 @pytest.mark.parametrize("n", [16, 64, 256])
 def test_rdivp(gpu, O, n):
     """test/slice_matrices.jl:226-234: rdivp!(u, t, tmp, pivot) ≈ U*P'/UpperTriangular(T)"""
