@@ -368,30 +368,62 @@ __device__ __noinline__ void lu4_wave(int n, const double *__restrict__ Gall, lo
             for (int Jb = 0; Jb < 4; ++Jb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) az[Jb][r] = Gin[t + (long)n * (site0p + 16 * Jb + 4 * r + g)];
-            {   // R0 block: thread -> column t' = tid / 4 of this chunk, 16 consecutive sites of the previous one
+            // R0 block: thread -> column t' = tid / 4 of this chunk, 16 consecutive sites of the previous one
+            double2 r0v[8];
+            {
                 const int tl = tid >> 2, s0 = (tid & 3) * 16;
                 const double2 *q = reinterpret_cast<const double2 *>(Gin + (long)n * (site0 + tl) + site0p + s0);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) r0v[i] = q[i];
+            }
+            // the images of the previous chunk (the 80 operands of the two triangles, x): NB == 1 stages them in LDS
+            // behind the shared structure, all four waves copying together, so that the whole prologue needs ONE memory
+            // round trip (G columns, R0 block and images in flight together) and no operand lives in a register
+            // before its MFMA; NB == 2 has no LDS left for that and requests the operands into registers
+            constexpr bool STAGE = sizeof(Lu4Smem<NB>) + LU_STRIDE * sizeof(double) <= 150 * 1024;
+            double *imgl = lu4_lds + (sizeof(Lu4Smem<NB>) + 15) / 16 * 2;
+            double opU[STAGE ? 1 : 6][4], opL[STAGE ? 1 : 6][4], opP[STAGE ? 1 : 4][4], opQ[STAGE ? 1 : 4][4], xr[4][4];
+            if (STAGE) {
+                constexpr int NI = (LU_STRIDE / 2 + 255) / 256;
+                const double2 *src = reinterpret_cast<const double2 *>(imgp);
+                double2 *dst = reinterpret_cast<double2 *>(imgl);
+                double2 iv[NI];
+#pragma unroll
+                for (int i = 0; i < NI; ++i) iv[i] = src[min(tid + 256 * i, LU_STRIDE / 2 - 1)];
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+                    if (tid + 256 * i < LU_STRIDE / 2) dst[tid + 256 * i] = iv[i];
+            } else {
+#pragma unroll
+                for (int pr = 0; pr < (STAGE ? 0 : 6); ++pr)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        opU[pr][q] = imgp[LU_OFF_U + pr * LU_TILE + q * 64 + lane];
+                        opL[pr][q] = imgp[LU_OFF_L + pr * LU_TILE + q * 64 + lane];
+                    }
+#pragma unroll
+                for (int Jb = 0; Jb < (STAGE ? 0 : 4); ++Jb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        opP[Jb][q] = imgp[LU_OFF_PT + Jb * LU_TILE + q * 64 + lane];
+                        opQ[Jb][q] = imgp[LU_OFF_Q + Jb * LU_TILE + q * 64 + lane];
+                    }
+            }
+            {   // (all loads of the prologue are in flight by now: one round trip)
+                const int tl = tid >> 2, s0 = (tid & 3) * 16;
                 double2 *d = reinterpret_cast<double2 *>(Rl + tl * 66 + s0);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) d[i] = q[i];
+                for (int i = 0; i < 8; ++i) d[i] = r0v[i];
             }
-            // all 80 operands of the two triangles requested at once (from L2), before the dependent MFMA chain
-            double opU[6][4], opL[6][4], opP[4][4], opQ[4][4], xr[4][4];
-#pragma unroll
-            for (int pr = 0; pr < 6; ++pr)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    opU[pr][q] = imgp[LU_OFF_U + pr * LU_TILE + q * 64 + lane];
-                    opL[pr][q] = imgp[LU_OFF_L + pr * LU_TILE + q * 64 + lane];
-                }
+            if (STAGE) __syncthreads();  // images (and the R0 block) are in LDS
 #pragma unroll
             for (int Jb = 0; Jb < 4; ++Jb)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    opP[Jb][q] = imgp[LU_OFF_PT + Jb * LU_TILE + q * 64 + lane];
-                    opQ[Jb][q] = imgp[LU_OFF_Q + Jb * LU_TILE + q * 64 + lane];
-                    xr[Jb][q] = imgp[LU_IMG + 16 * Jb + 4 * q + g];
-                }
+                for (int q = 0; q < 4; ++q) xr[Jb][q] = STAGE ? imgl[LU_IMG + 16 * Jb + 4 * q + g] : imgp[LU_IMG + 16 * Jb + 4 * q + g];
+#define PRO_U(pr, q) (STAGE ? imgl[LU_OFF_U + (pr) * LU_TILE + (q) * 64 + lane] : opU[STAGE ? 0 : (pr)][q])
+#define PRO_L(pr, q) (STAGE ? imgl[LU_OFF_L + (pr) * LU_TILE + (q) * 64 + lane] : opL[STAGE ? 0 : (pr)][q])
+#define PRO_P(jb, q) (STAGE ? imgl[LU_OFF_PT + (jb) * LU_TILE + (q) * 64 + lane] : opP[STAGE ? 0 : (jb)][q])
+#define PRO_Q(jb, q) (STAGE ? imgl[LU_OFF_Q + (jb) * LU_TILE + (q) * 64 + lane] : opQ[STAGE ? 0 : (jb)][q])
             d4 xz[4], tt[4];
 #ifdef LU4_STAMPS
             LU4_STAMP(400 + 8 * J + 1);
@@ -403,10 +435,10 @@ __device__ __noinline__ void lu4_wave(int n, const double *__restrict__ Gall, lo
 #pragma unroll
                 for (int K = 0; K < Jb; ++K)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) az[Jb] = MFMA(opU[lu_pair(K, Jb)][q], xz[K][q], az[Jb]);
+                    for (int q = 0; q < 4; ++q) az[Jb] = MFMA(PRO_U(lu_pair(K, Jb), q), xz[K][q], az[Jb]);
                 d4 z = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int q = 0; q < 4; ++q) z = MFMA(opP[Jb][q], az[Jb][q], z);
+                for (int q = 0; q < 4; ++q) z = MFMA(PRO_P(Jb, q), az[Jb][q], z);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) xz[Jb][r] = z[r] * xr[Jb][r];
             }
@@ -416,14 +448,18 @@ __device__ __noinline__ void lu4_wave(int n, const double *__restrict__ Gall, lo
 #pragma unroll
                 for (int K = Jb + 1; K < 4; ++K)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) a = MFMA(opL[lu_pair(Jb, K)][q], tt[K][q], a);
+                    for (int q = 0; q < 4; ++q) a = MFMA(PRO_L(lu_pair(Jb, K), q), tt[K][q], a);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) a[r] = xz[Jb][r] + xr[Jb][r] * a[r];
                 d4 o = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int q = 0; q < 4; ++q) o = MFMA(opQ[Jb][q], a[q], o);
+                for (int q = 0; q < 4; ++q) o = MFMA(PRO_Q(Jb, q), a[q], o);
                 tt[Jb] = o;
             }
+#undef PRO_U
+#undef PRO_L
+#undef PRO_P
+#undef PRO_Q
             LU4_STAMP(400 + 8 * J + 3);
             if (J < 3) {
 #pragma unroll
@@ -1035,7 +1071,10 @@ hipError_t launch_sweep_fused(int n, int nb, int n_walkers, const double *Gin, d
     const int flush_blocks = groups * 8 * a.tiles_m * a.tiles_n;
     const size_t lds_flush = ((size_t)LU_STRIDE + 16 * nt * FL_LDR) * sizeof(double);
     const size_t lds_lu = nb == 1 ? sizeof(Lu4Smem<1>) : sizeof(Lu4Smem<2>);
-    const size_t lds = lds_flush > lds_lu ? lds_flush : lds_lu;
+    // NB == 1: the prologue stages the previous chunk's images behind the shared structure (lu4_wave, STAGE)
+    const size_t lds_pro = nb == 1 ? (sizeof(Lu4Smem<1>) + 15) / 16 * 16 + LU_STRIDE * sizeof(double) : lds_lu;
+    const size_t lds_e = lds_pro > lds_lu ? lds_pro : lds_lu;
+    const size_t lds = lds_flush > lds_e ? lds_flush : lds_e;
     int dev = 0;
     (void)hipGetDevice(&dev);
     static unsigned attr_mask = 0;
