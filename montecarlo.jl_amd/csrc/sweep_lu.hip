@@ -506,9 +506,11 @@ __device__ __noinline__ void lu4_wave(int n, const double *__restrict__ Gall, lo
 #pragma unroll
     for (int I0 = 0; I0 < 4; ++I0) {
         if (!FULL && 16 * I0 >= nsites) break;
-        // the triangular inverses ride on wave I0 + 2: not on the next pivot (I0 + 1), whose lag at the end of the
-        // block is the hand-over time
-        const bool PIV = (I0 == J), HLP = (J > I0), PTQ = (J == ((I0 + 2) & 3));
+        // the triangular inverses ride on a wave that is idle in this block (wave 0 after its own block, wave 1 in the
+        // last one); in block 0 everybody is busy and they go to wave 3, whose lag has three blocks to drain - never to
+        // the next pivot (I0 + 1), whose lag at the end of the block is the hand-over time (stamps: with the inverses of
+        // block 0 on wave 2 that wave entered block 2 about 4000 cycles behind)
+        const bool PIV = (I0 == J), HLP = (J > I0), PTQ = (J == (I0 == 0 ? 3 : (I0 == 3 ? 1 : 0)));
         if (!PIV && !HLP && !PTQ) continue;
         d4 PT[NB], Q[NB];
         if (PTQ) {
@@ -573,12 +575,15 @@ __device__ __noinline__ void lu4_wave(int n, const double *__restrict__ Gall, lo
                     constexpr int dummy = 0;
                     (void)dummy;
                     const int c1 = c + 1, l1 = 16 * (c1 & 3) + c1;  // lane of S[s+1][s+1] in register c1 >> 2
-                    if (__builtin_amdgcn_readfirstlane((int)acc)) {
-                        accb |= 1u << c;
+                    {
+                        // branch-free in the decision: a rejected site runs the same stream with x = 0 (its two MFMAs add
+                        // zero; a branch costs more in register copies at the join than the MFMA issue slots it saves)
+                        const bool accu = __builtin_amdgcn_readfirstlane((int)acc) != 0;
+                        accb |= (accu ? 1u : 0u) << c;
                         const bool lm2 = g == ks && ci > c;
 #pragma unroll
                         for (int b = 0; b < NB; ++b) {
-                            const double x = xb[b];
+                            const double x = accu ? xb[b] : 0.0;
                             const double mS = lm2 ? S[b][J][r0] : 0.0, mT = lm2 ? ST[b][J][r0] : 0.0;
                             const double aS = x * mT, aT = x * mS;
                             if (more) {
@@ -591,13 +596,7 @@ __device__ __noinline__ void lu4_wave(int n, const double *__restrict__ Gall, lo
                             ST[b][J] = MFMA(aT, mT, ST[b][J]);
                         }
                         LU4_ORDER();
-                        __hip_atomic_store(&sm.step[s], word | 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    } else {
-                        __hip_atomic_store(&sm.step[s], word | 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (more) {
-#pragma unroll
-                            for (int b = 0; b < NB; ++b) dcur[b] = readlane_d(S[b][J][c1 >> 2], l1);
-                        }
+                        __hip_atomic_store(&sm.step[s], word | (accu ? 2 : 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                     lastflag = word;
                 } else {
@@ -982,13 +981,13 @@ __device__ __forceinline__ void flush_lu_body(int bid, int n, int n_units, const
     }
 }
 
-template <bool FULL, int NT>
+template <bool FULL, int NT, int NCP = 1>
 __global__ __launch_bounds__(256) void sweep_flush_lu_kernel(int n, int n_units, const double *__restrict__ Gin_all,
                                                             double *__restrict__ Gout_all, long strideG, int site0,
                                                             int nsites, const double *__restrict__ img_all,
                                                             int tiles_m, int tiles_n)
 {
-    flush_lu_body<FULL, NT>(blockIdx.x, n, n_units, Gin_all, Gout_all, strideG, site0, nsites, img_all, tiles_m, tiles_n);
+    flush_lu_body<FULL, NT, NCP>(blockIdx.x, n, n_units, Gin_all, Gout_all, strideG, site0, nsites, img_all, tiles_m, tiles_n);
 }
 
 // One launch per chunk boundary: the first n_walkers workgroups eliminate chunk `site0` (adding the not yet applied
@@ -1044,6 +1043,18 @@ hipError_t launch_sweep_flush_lu(int n, int n_units, const double *Gin, double *
 #define FL_LAUNCH(FU, NTV)                                                                                          \
     hipExtLaunchKernelGGL((sweep_flush_lu_kernel<FU, NTV>), dim3(groups * 8 * tm * tn), dim3(256), lds, s, start, stop, 0, \
                           n, n_units, Gin, Gout, strideG, site0, nsites, img, tm, tn)
+    static const bool ncp2 = getenv("DQMC_FLUSH_NCP2") != nullptr;  // experiment: two column passes per workgroup
+    if (ncp2 && wide && full && n % 256 == 0) {
+        static unsigned m2 = 0;
+        if (!(m2 & (1u << dev))) {
+            (void)hipFuncSetAttribute((const void *)sweep_flush_lu_kernel<true, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)(((size_t)LU_STRIDE + 128 * FL_LDR) * sizeof(double)));
+            m2 |= 1u << dev;
+        }
+        hipExtLaunchKernelGGL((sweep_flush_lu_kernel<true, 8, 2>), dim3(groups * 8 * tm * (tn / 2)), dim3(256), lds, s, start, stop,
+                              0, n, n_units, Gin, Gout, strideG, site0, nsites, img, tm, tn / 2);
+        return hipGetLastError();
+    }
     if (wide) { if (full) FL_LAUNCH(true, 8); else FL_LAUNCH(false, 8); }
     else { if (full) FL_LAUNCH(true, 4); else FL_LAUNCH(false, 4); }
 #undef FL_LAUNCH
