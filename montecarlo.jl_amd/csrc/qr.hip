@@ -594,11 +594,36 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v)
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// sqrt(x) and 1/sqrt(x) together (coupled Goldschmidt iterations from v_rsq_f64, then one correction of the root);
+// x > 0 and far from the ends of the exponent range
+__device__ __forceinline__ void qb_sqrt_rsqrt(double x, double &root, double &rroot)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    const double d = __builtin_fma(-g, g, x);
+    root = __builtin_fma(d, h, g);
+    rroot = h + h;
+}
+// 1/x from v_rcp_f64 and two Newton steps (no scaling, no special cases: x is a column norm scale)
+__device__ __forceinline__ double qb_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-x, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
 // reflectorApply! (UDT.jl:32-50) on one register-resident column, followed by its fresh squared norm.
 // KB0 = first live block of 8 rows: in the region of steps 32 R .. 32 R + 31 rows below 32 R are finished
 // (the reflector is zero there), so blocks k < 4 R cost nothing at compile time.
 template <int KB0>
-__device__ __forceinline__ double qc_apply(double (&x)[32], const double *vq, double tj, int j, int rg)
+__device__ __forceinline__ double qc_apply(double (&x)[32], const double *vq, double rcp, double trr, int j, int rg)
 {
     double2 vv[16];
     double d0 = 0.0, d1 = 0.0;
@@ -608,7 +633,8 @@ __device__ __forceinline__ double qc_apply(double (&x)[32], const double *vq, do
         d0 += vv[k >> 1].x * x[k];
         d1 += vv[k >> 1].y * x[k + 1];
     }
-    const double wv = sum8(d0 + d1) * tj;
+    // vq holds the UNSCALED reflector u = xi v (u_j = xi): H x = x - u (tj / xi^2) (u' x)
+    const double wv = (sum8(d0 + d1) * rcp) * trr;
     double n0 = 0.0, n1 = 0.0;
 #pragma unroll
     for (int k = KB0; k < 32; k += 2) {
@@ -732,7 +758,8 @@ __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double
                 lbc = better ? qc : lbc;
             }
         }
-        // ---- its owner lanes put the column into LDS
+        // ---- its owner lanes put the column into LDS (measured: letting every wave extract its own candidate before
+        // the first barrier instead, as qr_tail_kernel does, saves this barrier but costs 140 ns per step here)
         if (lbc >= 0 && w == ((lbc >> 3) >> 3)) {
             if (cg == ((lbc >> 3) & 7)) {  // exec-masked: the other lane groups issue no LDS writes at all
                 double2 *dst = reinterpret_cast<double2 *>(colbuf + rg * QT_VS);
@@ -817,11 +844,13 @@ __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double
         if (cm < 0) { cm = cj; jm = j; maxval = 0.0; wpart = cm & 7; }  // nothing live: cannot happen for j < n
         // ---- reflector scalars (UDT.jl:133-148) from the header alone; they overlap the column fetch below
         // (branch-free: a zero column, maxval == 0, keeps tau = 0 and the column as it is)
-        const double rootn = sqrt(maxval);
         const bool nz = maxval != 0.0;
+        double rootn, rrootn;
+        qb_sqrt_rsqrt(nz ? maxval : 1.0, rootn, rrootn);
         const double nu = nz ? copysign(rootn, xi1) : 1.0;
         const double xi = nz ? xi1 + nu : 1.0;
-        const double tj = nz ? xi / nu : 0.0;
+        const double tj = nz ? __builtin_fma(fabs(xi1), rrootn, 1.0) : 0.0;  // xi / nu
+        const double rcp = qb_rcp(xi), trr = tj * rcp;
         // ---- the winning column (tagged packets), output column j
         double cv = 0.0;
         {
@@ -831,9 +860,8 @@ __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double
         }
         {
             const int r = tid;
-            const double scaled = cv / xi;
-            double outv = (nz && r == j) ? -nu : ((nz && r > j) ? scaled : cv);
-            double vr = (r == j) ? 1.0 : ((nz && r > j) ? scaled : 0.0);
+            double outv = (nz && r == j) ? -nu : ((nz && r > j) ? cv * rcp : cv);
+            double vr = (r == j) ? xi : ((nz && r > j) ? cv : 0.0);  // unscaled: u = xi v
             if (r >= n) vr = 0.0;
             vperm[(r & 7) * QT_VS + (r >> 3)] = vr;
             if (part == wpart && r < n) Wo[r + (long)n * j] = outv;  // the owner writes the finished column
@@ -854,14 +882,14 @@ __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double
         if (c < n && mypos > j) {
             const double *vq = vperm + rg * QT_VS;
             switch (j >> 5) {  // wave-uniform: region of 32 steps -> first live row block
-            case 0: nrm = qc_apply<0>(x, vq, tj, j, rg); break;
-            case 1: nrm = qc_apply<4>(x, vq, tj, j, rg); break;
-            case 2: nrm = qc_apply<8>(x, vq, tj, j, rg); break;
-            case 3: nrm = qc_apply<12>(x, vq, tj, j, rg); break;
-            case 4: nrm = qc_apply<16>(x, vq, tj, j, rg); break;
-            case 5: nrm = qc_apply<20>(x, vq, tj, j, rg); break;
-            case 6: nrm = qc_apply<24>(x, vq, tj, j, rg); break;
-            default: nrm = qc_apply<28>(x, vq, tj, j, rg); break;
+            case 0: nrm = qc_apply<0>(x, vq, rcp, trr, j, rg); break;
+            case 1: nrm = qc_apply<4>(x, vq, rcp, trr, j, rg); break;
+            case 2: nrm = qc_apply<8>(x, vq, rcp, trr, j, rg); break;
+            case 3: nrm = qc_apply<12>(x, vq, rcp, trr, j, rg); break;
+            case 4: nrm = qc_apply<16>(x, vq, rcp, trr, j, rg); break;
+            case 5: nrm = qc_apply<20>(x, vq, rcp, trr, j, rg); break;
+            case 6: nrm = qc_apply<24>(x, vq, rcp, trr, j, rg); break;
+            default: nrm = qc_apply<28>(x, vq, rcp, trr, j, rg); break;
             }
         }
         // (pos/colat are rewritten by thread 0 only after the barriers of the next step)
@@ -922,31 +950,6 @@ struct QbShared {
     int colid[G::M];                                   // slot -> original column
 };
 
-// sqrt(x) and 1/sqrt(x) together (coupled Goldschmidt iterations from v_rsq_f64, then one correction of the root);
-// x > 0 and far from the ends of the exponent range
-__device__ __forceinline__ void qb_sqrt_rsqrt(double x, double &root, double &rroot)
-{
-    const double y = __builtin_amdgcn_rsq(x);
-    double g = x * y, h = 0.5 * y;
-    double r = __builtin_fma(-h, g, 0.5);
-    g = __builtin_fma(g, r, g);
-    h = __builtin_fma(h, r, h);
-    r = __builtin_fma(-h, g, 0.5);
-    g = __builtin_fma(g, r, g);
-    h = __builtin_fma(h, r, h);
-    const double d = __builtin_fma(-g, g, x);
-    root = __builtin_fma(d, h, g);
-    rroot = h + h;
-}
-// 1/x from v_rcp_f64 and two Newton steps (no scaling, no special cases: x is a column norm scale)
-__device__ __forceinline__ double qb_rcp(double x)
-{
-    double r = __builtin_amdgcn_rcp(x);
-    double e = __builtin_fma(-x, r, 1.0);
-    r = __builtin_fma(r, e, r);
-    e = __builtin_fma(-x, r, 1.0);
-    return __builtin_fma(r, e, r);
-}
 // candidate b replaces a: larger norm, then smaller position (bitwise logic: no branches)
 __device__ __forceinline__ void qb_merge(double &an, int &ap, int &as, double bn, int bp, int bs)
 {
