@@ -1043,7 +1043,16 @@ hipError_t launch_sweep_flush_lu(int n, int n_units, const double *Gin, double *
 #define FL_LAUNCH(FU, NTV)                                                                                          \
     hipExtLaunchKernelGGL((sweep_flush_lu_kernel<FU, NTV>), dim3(groups * 8 * tm * tn), dim3(256), lds, s, start, stop, 0, \
                           n, n_units, Gin, Gout, strideG, site0, nsites, img, tm, tn)
-    static const bool ncp2 = getenv("DQMC_FLUSH_NCP2") != nullptr;  // experiment: two column passes per workgroup
+    // two column passes per workgroup (one pair of triangular solves per 64-row tile instead of two) when the grid is
+    // more than one round of workgroups anyway: 512 units (config 4 on one GPU) 293 -> 230 us; a single round
+    // (32 units: 256 workgroups) is faster with one pass each (16.7 vs 24 us).  DQMC_FLUSH_NCP2 forces it.
+    const bool ncp2_env = getenv("DQMC_FLUSH_NCP2") != nullptr;  // (read per launch: the tests toggle it)
+    static int n_cus[32] = {0};
+    if (dev >= 0 && dev < 32 && n_cus[dev] == 0) {
+        hipDeviceProp_t prop;
+        n_cus[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
+    }
+    const bool ncp2 = ncp2_env || (dev >= 0 && dev < 32 && groups * 8 * tm * tn > n_cus[dev]);
     if (ncp2 && wide && full && n % 256 == 0) {
         static unsigned m2 = 0;
         if (!(m2 & (1u << dev))) {

@@ -237,17 +237,17 @@ def test_cooperative_qr_timeout_falls_back(gpu, O):
     assert "fallbacks" in p.stdout
 
 
-@pytest.mark.parametrize("switch", ["DQMC_NO_SLAB", "DQMC_SWEEP_SPLIT", "DQMC_QR_TAIL"])
-def test_fast_paths_against_their_plain_forms(gpu, switch):
+@pytest.mark.parametrize("plain", [{"DQMC_NO_SLAB": "1"}, {"DQMC_SWEEP_SPLIT": "1"}, {"DQMC_QR_TAIL": "0"},
+                                   {"DQMC_SWEEP_SPLIT": "1", "DQMC_FLUSH_NCP2": "1"}],
+                         ids=["slab_chains", "fused_sweep", "two_phase_qr", "two_pass_flush"])
+def test_fast_paths_against_their_plain_forms(gpu, plain):
     """The round-2 launch forms at n = 256 (slab-resident product chains, elimination fused with the previous chunk's
-    flush, two-phase QR) against the forms they replace, selected per handle through the environment: same seeds,
-    HS field identical, G within the parity tolerance (the forms differ by reassociation only)."""
+    flush, two-phase QR; the two-pass flush of the throughput regime against the one-pass one) against the forms they
+    replace, selected per handle / per launch through the environment: same seeds, HS field identical, G within the
+    parity tolerance (the forms differ by reassociation only)."""
     def run(env):
-        old = os.environ.get(switch)
-        if env is None:
-            os.environ.pop(switch, None)
-        else:
-            os.environ[switch] = env
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
         try:
             mc = gpu.DQMC(gpu.HubbardModelAttractive(16, 2), beta=2.0, n_walkers=2, seed=7)
             mc.prepare()
@@ -256,12 +256,13 @@ def test_fast_paths_against_their_plain_forms(gpu, switch):
             mc.close()
             return out
         finally:
-            if old is None:
-                os.environ.pop(switch, None)
-            else:
-                os.environ[switch] = old
-    conf_fast, g_fast = run(None)
-    conf_plain, g_plain = run("0" if switch == "DQMC_QR_TAIL" else "1")
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+    conf_fast, g_fast = run({})
+    conf_plain, g_plain = run(plain)
     for w in range(2):
         assert np.array_equal(conf_fast[w], conf_plain[w])
         assert relerr(g_fast[w], g_plain[w]) < TOL
