@@ -51,21 +51,6 @@ __global__ __launch_bounds__(256) void slab_chain_kernel(SlabArgs a)
     double *buf0 = slab_lds, *buf1 = slab_lds + SL_W * SL_LD;
     const long conf_off = (long)wk * a.conf_stride;
 
-    // ---- X_0 slab -> LDS, scaled by pre_1
-    {
-        const double *X0 = a.X0 + (long)unit * a.x_su + (long)blk * a.x_sb + (long)SL_N * (SL_W * slab);
-        const int col = tid >> 3, r0 = 32 * (tid & 7);
-        const int8_t *pc = a.st[0].pre_conf ? a.st[0].pre_conf + conf_off : nullptr;
-#pragma unroll
-        for (int i = 0; i < 32; i += 2) {
-            double2 v = *reinterpret_cast<const double2 *>(X0 + (long)SL_N * col + r0 + i);
-            if (pc) {
-                v.x *= slab_conf_val(pc, r0 + i, a.st[0].pre_sign, blk, a.epl, a.eml);
-                v.y *= slab_conf_val(pc, r0 + i + 1, a.st[0].pre_sign, blk, a.epl, a.eml);
-            }
-            *reinterpret_cast<double2 *>(buf0 + col * SL_LD + r0 + i) = v;
-        }
-    }
     // my A rows: tile row ci <-> matrix row 4 (ci & 3) + (ci >> 2) of each 16-row tile; k = 8 p + 2 g (+ 1)
     const int arow = 64 * w + 4 * (ci & 3) + (ci >> 2);
     auto a_ptr = [&](int s) {
@@ -88,7 +73,22 @@ __global__ __launch_bounds__(256) void slab_chain_kernel(SlabArgs a)
         ++q_issue;
     };
 #pragma unroll
-    for (int i = 0; i < SL_RING - 1; ++i) issue(i);
+    for (int i = 0; i < SL_RING - 1; ++i) issue(i);  // first A operands in flight (HBM latency) before X_0 is staged
+    // ---- X_0 slab -> LDS, scaled by pre_1
+    {
+        const double *X0 = a.X0 + (long)unit * a.x_su + (long)blk * a.x_sb + (long)SL_N * (SL_W * slab);
+        const int col = tid >> 3, r0 = 32 * (tid & 7);
+        const int8_t *pc = a.st[0].pre_conf ? a.st[0].pre_conf + conf_off : nullptr;
+#pragma unroll
+        for (int i = 0; i < 32; i += 2) {
+            double2 v = *reinterpret_cast<const double2 *>(X0 + (long)SL_N * col + r0 + i);
+            if (pc) {
+                v.x *= slab_conf_val(pc, r0 + i, a.st[0].pre_sign, blk, a.epl, a.eml);
+                v.y *= slab_conf_val(pc, r0 + i + 1, a.st[0].pre_sign, blk, a.epl, a.eml);
+            }
+            *reinterpret_cast<double2 *>(buf0 + col * SL_LD + r0 + i) = v;
+        }
+    }
     __syncthreads();
 
     d4 acc[4][2];
