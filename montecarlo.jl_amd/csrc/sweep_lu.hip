@@ -841,8 +841,10 @@ constexpr int FL_LDR = 66;  // row stride of the R0 tile in LDS (doubles): ci * 
 template <bool FULL, int NT, int NCP = 1>
 __device__ __forceinline__ void flush_lu_body(int bid, int n, int n_units, const double *__restrict__ Gin_all,
                                               double *__restrict__ Gout_all, long strideG, int site0, int nsites,
-                                              const double *__restrict__ img_all, int tiles_m, int tiles_n)
+                                              const double *__restrict__ img_all, int tiles_m, int tiles_n,
+                                              int ncp_rt = 1)  // NCP == 0: the pass count is this run-time value
 {
+    const int ncp = NCP > 0 ? NCP : ncp_rt;
     double *fsm = lu4_lds;
     double *img = fsm;                 // [LU_IMG + 64]
     double *xs = fsm + LU_IMG;
@@ -852,7 +854,7 @@ __device__ __forceinline__ void flush_lu_body(int bid, int n, int n_units, const
     const int unit = (seq / T) * 8 + xcd;
     if (unit >= n_units) return;
     const int tile = seq % T;
-    const int m0 = (tile % tiles_m) * 64, n00 = (tile / tiles_m) * (16 * NT * NCP);
+    const int m0 = (tile % tiles_m) * 64, n00 = (tile / tiles_m) * (16 * NT * ncp);
     int n0 = n00;
     const double *__restrict__ Gin = Gin_all + (long)unit * strideG;
     double *__restrict__ Gout = Gout_all + (long)unit * strideG;
@@ -935,7 +937,7 @@ __device__ __forceinline__ void flush_lu_body(int bid, int n, int n_units, const
         for (int q = 0; q < 4; ++q) o = MFMA(img[LU_OFF_Q + J * LU_TILE + q * 64 + lane], a[q], o);
         tt[J] = o;
     }
-    for (int cp = 0; cp < NCP; ++cp) {
+    for (int cp = 0; cp < ncp; ++cp) {
         if (cp > 0) {  // next 16 NT columns: G tile and R0 tile again (the solves are done)
             n0 = n00 + cp * 16 * NT;
 #pragma unroll
@@ -985,9 +987,10 @@ template <bool FULL, int NT, int NCP = 1>
 __global__ __launch_bounds__(256) void sweep_flush_lu_kernel(int n, int n_units, const double *__restrict__ Gin_all,
                                                             double *__restrict__ Gout_all, long strideG, int site0,
                                                             int nsites, const double *__restrict__ img_all,
-                                                            int tiles_m, int tiles_n)
+                                                            int tiles_m, int tiles_n, int ncp_rt)
 {
-    flush_lu_body<FULL, NT, NCP>(blockIdx.x, n, n_units, Gin_all, Gout_all, strideG, site0, nsites, img_all, tiles_m, tiles_n);
+    flush_lu_body<FULL, NT, NCP>(blockIdx.x, n, n_units, Gin_all, Gout_all, strideG, site0, nsites, img_all, tiles_m, tiles_n,
+                                 ncp_rt);
 }
 
 // One launch per chunk boundary: the first n_walkers workgroups eliminate chunk `site0` (adding the not yet applied
@@ -1042,7 +1045,7 @@ hipError_t launch_sweep_flush_lu(int n, int n_units, const double *Gin, double *
     }
 #define FL_LAUNCH(FU, NTV)                                                                                          \
     hipExtLaunchKernelGGL((sweep_flush_lu_kernel<FU, NTV>), dim3(groups * 8 * tm * tn), dim3(256), lds, s, start, stop, 0, \
-                          n, n_units, Gin, Gout, strideG, site0, nsites, img, tm, tn)
+                          n, n_units, Gin, Gout, strideG, site0, nsites, img, tm, tn, 1)
     // two column passes per workgroup (one pair of triangular solves per 64-row tile instead of two) when the grid is
     // more than one round of workgroups anyway: 512 units (config 4 on one GPU) 293 -> 230 us; a single round
     // (32 units: 256 workgroups) is faster with one pass each (16.7 vs 24 us).  DQMC_FLUSH_NCP2 forces it.
@@ -1061,7 +1064,20 @@ hipError_t launch_sweep_flush_lu(int n, int n_units, const double *Gin, double *
             m2 |= 1u << dev;
         }
         hipExtLaunchKernelGGL((sweep_flush_lu_kernel<true, 8, 2>), dim3(groups * 8 * tm * (tn / 2)), dim3(256), lds, s, start, stop,
-                              0, n, n_units, Gin, Gout, strideG, site0, nsites, img, tm, tn / 2);
+                              0, n, n_units, Gin, Gout, strideG, site0, nsites, img, tm, tn / 2, 2);
+        return hipGetLastError();
+    }
+    // n not a multiple of 128 (64-column tiles, e.g. n = 576: 9 x 9 tiles per unit, every row tile's solves done 9
+    // times over) and more than one round of workgroups: ONE workgroup per 64-row tile, all column tiles in passes
+    if (ncp2 && !wide && full && tn > 1) {
+        static unsigned m0 = 0;
+        if (!(m0 & (1u << dev))) {
+            (void)hipFuncSetAttribute((const void *)sweep_flush_lu_kernel<true, 4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)(((size_t)LU_STRIDE + 128 * FL_LDR) * sizeof(double)));
+            m0 |= 1u << dev;
+        }
+        hipExtLaunchKernelGGL((sweep_flush_lu_kernel<true, 4, 0>), dim3(groups * 8 * tm), dim3(256), lds, s, start, stop, 0, n,
+                              n_units, Gin, Gout, strideG, site0, nsites, img, tm, 1, tn);
         return hipGetLastError();
     }
     if (wide) { if (full) FL_LAUNCH(true, 8); else FL_LAUNCH(false, 8); }
