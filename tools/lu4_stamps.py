@@ -34,6 +34,11 @@ for rep in range(3):
     print(" pivot step deltas: block0 %s" % d[:15].tolist())
     print("                    block1 %s" % d[16:31].tolist())
     print("   block transitions:", int(piv[16] - piv[15]), int(piv[32] - piv[31]), int(piv[48] - piv[47]))
+    for J in (1, 2, 3):  # hand-over to wave J: last decision of block J-1 -> its payload seen by J -> J's block end -> J decides
+        sl = 16 * J - 1
+        hJ = t[64 * (1 + J):64 * (2 + J)]
+        print(" hand-over %d->%d: payload of site %d seen +%d, panel/strips done +%d, first decision +%d (cycles after that site's decision stamp)" % (
+            J - 1, J, sl, hJ[sl] - piv[sl], t[320 + 8 * J + 2 + (J - 1)] - piv[sl], piv[sl + 1] - piv[sl]))
     for J in (1, 2, 3):
         h = t[64 * (1 + J):64 * (2 + J)]
         lag = [int(h[s] - piv[s]) for s in range(0, 16 * J, 3)]
