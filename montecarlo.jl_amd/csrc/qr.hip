@@ -428,7 +428,8 @@ __global__ __launch_bounds__(QT_THREADS) void qr_tile256_kernel(int n, int nstep
                                                                double *__restrict__ tauall,
                                                                int *__restrict__ pivall,
                                                                const double *__restrict__ srcall, long strideSrc,
-                                                               int *guard, int guard_val)
+                                                               int *guard, int guard_val, double *__restrict__ Xall,
+                                                               long strideX)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     if (guard && guard[0] != guard_val) return;  // fallback use, see qr_pivot_kernel
@@ -486,6 +487,18 @@ __global__ __launch_bounds__(QT_THREADS) void qr_tile256_kernel(int n, int nstep
     QT_REGION(0) QT_REGION(1) QT_REGION(2) QT_REGION(3) QT_REGION(4) QT_REGION(5) QT_REGION(6) QT_REGION(7)
 #undef QT_REGION
     if (tid < n) piv[tid] = pv[tid];
+    // two-phase form (nsteps = 128 of n = 256, used when there are too many matrices for the cooperative kernel): the
+    // trailing columns are exactly the register-resident positions 128..255; they go to X by ORIGINAL column id, all
+    // rows, and qr_tail_kernel<128, 4> takes over with the position table just written
+    if (Xall && nsteps == 128 && n == 256) {
+        double *__restrict__ X = Xall + (long)unit * strideX;
+        double *__restrict__ c2 = X + 256l * pv[128 + pb] + rg, *__restrict__ c3 = X + 256l * pv[192 + pb] + rg;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            c2[8 * k] = x2[k];
+            c3[8 * k] = x3[k];
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1350,7 +1363,8 @@ int qr_coop_blocks_per_cu()
 }
 
 static hipError_t launch_qr_single(int n, int n_units, double *A, long strideA, double *tau, int *pivot,
-                                   const double *src, long strideSrc, int *guard, int guard_val, hipStream_t s)
+                                   const double *src, long strideSrc, int *guard, int guard_val, hipStream_t s,
+                                   double *X = nullptr, long strideX = 0, const int *never = nullptr)
 {
     static const bool no_tile = getenv("DQMC_QR_STREAM") != nullptr;
     if (n > 128 && n <= 256 && !no_tile) {
@@ -1363,9 +1377,16 @@ static hipError_t launch_qr_single(int n, int n_units, double *A, long strideA, 
                                       (int)lds_t);
             attr_mask |= 1u << dev;
         }
-        const int nsteps = n;
+        // X given (primary use with more matrices than the cooperative kernel can hold, n == 256): the tile kernel does
+        // the first 128 steps, qr_tail_kernel the rest; `never` is a word that never equals -1 (the tail's exit test)
+        const bool two_phase = X && never && n == 256 && !guard;
+        const int nsteps = two_phase ? 128 : n;
         hipLaunchKernelGGL(qr_tile256_kernel, dim3(n_units), dim3(QT_THREADS), lds_t, s, n, nsteps, A, strideA, tau, pivot,
-                           src, strideSrc, guard, guard_val);
+                           src, strideSrc, guard, guard_val, two_phase ? X : nullptr, strideX);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess || !two_phase) return e;
+        hipLaunchKernelGGL((qr_tail_kernel<128, 4>), dim3(n_units), dim3(256), 0, s, n_units, X, strideX, A, strideA, tau, pivot,
+                           never, -1);
         return hipGetLastError();
     }
     const size_t lds = 2 * 1024 * sizeof(double);
@@ -1425,7 +1446,9 @@ hipError_t launch_qr_pivot(int n, int n_units, double *A, long strideA, double *
                                     (int)(ws->epoch & 0x7fffffffull), s);
         }
     }
-    return launch_qr_single(n, n_units, A, strideA, tau, pivot, nullptr, 0, nullptr, 0, s);
+    const bool tail_ok = ws && ws->fb && ws->tail_j0 == 128;  // (fb[0] holds launch epochs >= 0, never -1)
+    return launch_qr_single(n, n_units, A, strideA, tau, pivot, nullptr, 0, nullptr, 0, s, tail_ok ? X : nullptr, strideX,
+                            tail_ok ? ws->fb : nullptr);
 }
 
 // D, V and T from the factored matrix (UDT.jl:268-306).  One workgroup per unit.

@@ -87,6 +87,28 @@ def test_two_phase_qr_against_cooperative_alone(gpu):
         assert relerr(D1[i], D0[i]) < 1e-12
 
 
+def test_two_phase_qr_many_units(gpu):
+    """more matrices than the cooperative kernel can hold (> 64 at n = 256): the single-workgroup tile kernel does the
+    first 128 steps and hands over to qr_tail_kernel; against the tile kernel alone (DQMC_QR_TAIL=0)"""
+    import os
+    rng = np.random.default_rng(6)
+    X = rng.standard_normal((72, 256, 256))
+    X[5] *= np.exp(rng.uniform(-20, 20, size=256))[None, :]
+    U1, D1, T1, p1 = gpu.udt_AVX_pivot(X, True)
+    os.environ["DQMC_QR_TAIL"] = "0"
+    try:
+        U0, D0, T0, p0 = gpu.udt_AVX_pivot(X, True)
+    finally:
+        del os.environ["DQMC_QR_TAIL"]
+    for i in (0, 5, 37, 71):
+        rec = (U1[i] * D1[i]) @ T1[i]
+        scale = np.abs(X[i]).max(axis=0)
+        assert (np.abs(rec - X[i]) / scale[None, :]).max() < 1e-12
+        assert relerr(U1[i].T @ U1[i], np.eye(256)) < 1e-12
+    assert np.array_equal(p0, p1)
+    assert relerr(D1, D0) < 1e-12
+
+
 @pytest.mark.parametrize("n", [16, 64, 256])
 def test_rdivp(gpu, O, n):
     """test/slice_matrices.jl:226-234: rdivp!(u, t, tmp, pivot) ≈ U*P'/UpperTriangular(T)"""
