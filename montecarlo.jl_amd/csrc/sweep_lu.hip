@@ -461,27 +461,38 @@ __device__ __noinline__ void lu4_wave(int n, const double *__restrict__ Gall, lo
 #undef PRO_P
 #undef PRO_Q
             LU4_STAMP(400 + 8 * J + 3);
-            if (J < 3) {
-#pragma unroll
-                for (int K = 0; K < 4; ++K)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) ttx[((J * 4 + K) * 4 + q) * 64 + lane] = tt[K][q];
-            }
-            __syncthreads();  // R0 block and the T' tiles of the other waves are in LDS
+            // Block update, five tile products of 16 MFMAs on every wave: wave J computes what needs ITS OWN T' rows -
+            // the S' tiles (I, J), I <= J, of its block column, and the S tiles (J, Jc), Jc >= J, of block ROW J.  The
+            // latter belong to wave Jc for Jc > J: they go there as deltas through LDS.  (Ownership by block column
+            // alone gave wave 3 eight products and wave 0 two, and needed every wave's T' in LDS.)
+            if (!STAGE) __syncthreads();  // the R0 block is in LDS (STAGE: covered by the barrier behind the staging)
             LU4_STAMP(400 + 8 * J + 4);
+            double *dlt = ttx;  // [pair (J, Jc)][4 regs][64 lanes]
 #pragma unroll
-            for (int I = 0; I <= J; ++I)
+            for (int K = 0; K < 4; ++K)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int sk = 16 * K + 4 * q + g;
+#pragma unroll
+                    for (int I = 0; I <= J; ++I)  // S' tile (I, J): rows of G in my block column, columns in block I
+                        ST[b][I] = MFMA(Rl[(16 * I + ci) * 66 + sk], tt[K][q], ST[b][I]);
+                    S[b][J] = MFMA(tt[K][q], Rl[(16 * J + ci) * 66 + sk], S[b][J]);  // S tile (J, J)
+                }
+#pragma unroll
+            for (int Jc = J + 1; Jc < 4; ++Jc) {  // S tile (J, Jc): rows in my block, columns in block Jc
+                d4 dl = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                 for (int K = 0; K < 4; ++K)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int sk = 16 * K + 4 * q + g;
-                        // S' tile (I, J): rows of G in my block column (my own T'), columns in block I
-                        ST[b][I] = MFMA(Rl[(16 * I + ci) * 66 + sk], tt[K][q], ST[b][I]);
-                        // S tile (I, J): rows in block I (T' of wave I), columns in my block
-                        const double ta = (I == J) ? tt[K][q] : ttx[((I * 4 + K) * 4 + q) * 64 + lane];
-                        S[b][I] = MFMA(ta, Rl[(16 * J + ci) * 66 + sk], S[b][I]);
-                    }
+                    for (int q = 0; q < 4; ++q) dl = MFMA(tt[K][q], Rl[(16 * Jc + ci) * 66 + 16 * K + 4 * q + g], dl);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dlt[(lu_pair(J, Jc) * 4 + r) * 64 + lane] = dl[r];
+            }
+            __syncthreads();  // the deltas of the waves to my left are in LDS
+#pragma unroll
+            for (int I = 0; I < J; ++I)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) S[b][I][r] += dlt[(lu_pair(I, J) * 4 + r) * 64 + lane];
             __syncthreads();  // scratch is free again (next block / the step ring)
         }
         LU4_STAMP(320 + 8 * J + 7);
