@@ -308,9 +308,11 @@ __device__ __forceinline__ double lu4_rcp(double r)
 extern __shared__ __attribute__((aligned(16))) double lu4_lds[];
 #ifdef LU4_STAMPS  // diagnostic build only (tools/lu4_stamps.py): cycle stamps of walker 0 into a buffer of their own
 __device__ long long *lu4_stamp_ptr = nullptr;
+// LU4_STAMPS == 2: only the coarse stamps (index >= 320: phases of a wave), which do not disturb the site loop
 #define LU4_STAMP(idx)                                                                       \
     do {                                                                                     \
-        if (w == 0 && (threadIdx.x & 63) == 0 && lu4_stamp_ptr) lu4_stamp_ptr[(idx)] = (long long)__builtin_amdgcn_s_memtime(); \
+        if ((LU4_STAMPS != 2 || (idx) >= 320) && w == 0 && (threadIdx.x & 63) == 0 && lu4_stamp_ptr)            \
+            lu4_stamp_ptr[(idx)] = (long long)__builtin_amdgcn_s_memtime();                  \
     } while (0)
 #else
 #define LU4_STAMP(idx) do { } while (0)
@@ -425,7 +427,7 @@ __device__ __noinline__ void lu4_wave(int n, const double *__restrict__ Gall, lo
 #define PRO_P(jb, q) (STAGE ? imgl[LU_OFF_PT + (jb) * LU_TILE + (q) * 64 + lane] : opP[STAGE ? 0 : (jb)][q])
 #define PRO_Q(jb, q) (STAGE ? imgl[LU_OFF_Q + (jb) * LU_TILE + (q) * 64 + lane] : opQ[STAGE ? 0 : (jb)][q])
             d4 xz[4], tt[4];
-#ifdef LU4_STAMPS
+#if defined(LU4_STAMPS) && LU4_STAMPS != 2
             LU4_STAMP(400 + 8 * J + 1);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             LU4_STAMP(400 + 8 * J + 2);
@@ -498,7 +500,7 @@ __device__ __noinline__ void lu4_wave(int n, const double *__restrict__ Gall, lo
         LU4_STAMP(320 + 8 * J + 7);
     }
     LU4_STAMP(320 + 8 * J + 0);
-#ifdef LU4_STAMPS
+#if defined(LU4_STAMPS) && LU4_STAMPS != 2
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     LU4_STAMP(320 + 8 * J + 1);
 #endif
