@@ -233,8 +233,11 @@ int dqmc_export_susceptibilities(dqmc_handle *h, void *device_out);
  * sums every `measure_rate` sweeps (DQMC.jl:429-436).  dqmc_reduce packs EVERY accumulator of the handle (Green's
  * function sums, correlations, pairing, susceptibilities - whichever are configured) and the DQMCAnalysis counters
  * of its walkers (prop_local, acc_local, MagnitudeStats sum / count / max / min, DQMC.jl:4-47) into one device
- * buffer [sums | 2 maxima | 2 minima] and runs ncclAllReduce (sum, max, min) over RCCL on the handle's stream; the
- * accumulators then hold the global sums on every rank and dqmc_get_reduced_stats the global counters.
+ * buffer [sums | 2 maxima | 2 minima] and runs ncclAllReduce (sum, max, min) over RCCL on the handle's stream.
+ * The global sums are read with dqmc_get_reduced (section by section, same layouts and sizes as the local getters)
+ * and the global counters with dqmc_get_reduced_stats.  The handle's own accumulators are NOT modified - they keep
+ * the local sums - so the reduction may be repeated at every measurement interval (each call reduces the sums
+ * accumulated so far since the last dqmc_reset_accumulators).
  * comm == NULL reduces over the walkers of this handle only.  A host that brings its own collective (MPI from
  * Julia, gloo in this repository's tests) uses dqmc_reduce_export -> reduce (sums, then maxima, then minima; layout
  * above) -> dqmc_reduce_import instead. */
@@ -248,6 +251,8 @@ int dqmc_reduce(dqmc_handle *h, dqmc_comm *comm);
 int dqmc_reduce_size(dqmc_handle *h, size_t *n_doubles /* sums + 4 */);
 int dqmc_reduce_export(dqmc_handle *h, double *host_out);
 int dqmc_reduce_import(dqmc_handle *h, const double *host_in);
+enum { DQMC_RED_GREENS = 0, DQMC_RED_CORRELATIONS = 1, DQMC_RED_PAIRING = 2, DQMC_RED_SUSCEPTIBILITIES = 3 };
+int dqmc_get_reduced(dqmc_handle *h, int32_t which, double *host_out);
 int dqmc_get_reduced_stats(dqmc_handle *h, dqmc_stats *out);
 
 /* ---- batched linalg primitives (unit parity with test/slice_matrices.jl) --

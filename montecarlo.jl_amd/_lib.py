@@ -109,6 +109,7 @@ SIGNATURES = {
     "dqmc_reduce_size": (C.c_int, [_H, C.POINTER(C.c_size_t)]),
     "dqmc_reduce_export": (C.c_int, [_H, _dp]),
     "dqmc_reduce_import": (C.c_int, [_H, _dp]),
+    "dqmc_get_reduced": (C.c_int, [_H, C.c_int32, _dp]),
     "dqmc_get_reduced_stats": (C.c_int, [_H, C.POINTER(Stats)]),
     "dqmc_vmul": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _dp, _dp, _dp]),
     "dqmc_udt_pivot": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _dp, _dp, _dp, _i64p, C.c_int32]),

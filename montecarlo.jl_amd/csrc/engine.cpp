@@ -289,7 +289,9 @@ static int set_ones(dqmc_handle *h, double *d)
 
 static int alloc_qr_workspace(dqmc_handle *h)
 {
-    // device-side error word (bit 0: cooperative QR hand-off timed out, bit 1: sweep elimination hand-off timed out)
+    // device-side error word (bit 1: a hand-off inside the sweep elimination kernel timed out; bit 0 is no longer set by
+    // anything: a cooperative-QR time-out is not an error since round 2, the guarded kernel behind the launch redoes
+    // the factorisation and dqmc_qr_fallbacks counts it)
     CHK(dalloc(h, &h->qr_ws.errflag, (size_t)1));
     if (h->n > 256) return 0;
     hipDeviceProp_t prop;
@@ -300,7 +302,11 @@ static int alloc_qr_workspace(dqmc_handle *h)
     // co-residency: what the occupancy API reports for the kernel on this device (its ~200 VGPRs admit 2 per CU)
     h->qr_ws.max_blocks = prop.multiProcessorCount * qr_coop_blocks_per_cu();
     h->qr_ws.epoch = 0;
-    if (const char *e = getenv("DQMC_QR_TAIL")) h->qr_ws.tail_j0 = atoi(e);  // A/B switch, read per handle
+    if (const char *e = getenv("DQMC_QR_TAIL")) h->qr_ws.tail_j0 = atoi(e);  // A/B switches, read per handle
+    h->qr_ws.force_sc1 = getenv("DQMC_QR_SC1") != nullptr;
+    h->qr_ws.no_coop = getenv("DQMC_QR_NOCOOP") != nullptr;
+    if (const char *e = getenv("DQMC_QR_FORCE_TIMEOUT"))
+        h->qr_ws.force_timeout = strncmp(e, "step:", 5) == 0 ? 2 + atoi(e + 5) : 1;
     return 0;
 }
 static int check_qr_workspace(dqmc_handle *h)
@@ -310,8 +316,7 @@ static int check_qr_workspace(dqmc_handle *h)
     HIPCHK(hipMemcpy(&e, h->qr_ws.errflag, sizeof(int), hipMemcpyDeviceToHost));
     if (e) {  // reported once: the flag is cleared, the data of the failed call is not trustworthy
         HIPCHK(hipMemset(h->qr_ws.errflag, 0, sizeof(int)));
-        return fail(h, DQMC_ERR_HIP, (e & 1) ? "cooperative QR: hand-off timed out (results of this call are invalid)"
-                                             : "sweep elimination: hand-off timed out (results of this call are invalid)");
+        return fail(h, DQMC_ERR_HIP, "sweep elimination: hand-off timed out (results of this call are invalid)");
     }
     return 0;
 }
@@ -1480,18 +1485,12 @@ static int red_pack(dqmc_handle *h)
     HIPCHK(hipMemcpy(h->red_buf + off, tail, sizeof(tail), hipMemcpyHostToDevice));
     return 0;
 }
+// The reduced sums stay in red_buf (read with dqmc_get_reduced): the handle's own accumulators keep the LOCAL sums, so
+// that the reduction can be repeated every measure_rate sweeps (DQMC.jl:429-436) - writing the global sums back into
+// them would count the earlier samples once per rank again at the next reduction.
 static int red_unpack(dqmc_handle *h)
 {
-    size_t off = 0;
-    auto get = [&](double *dst, size_t cnt) -> int {
-        if (cnt) HIPCHK(hipMemcpyAsync(dst, h->red_buf + off, cnt * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-        off += cnt;
-        return 0;
-    };
-    CHK(get(h->acc, h->acc_n));
-    CHK(get(h->corr_acc, h->corr_n));
-    CHK(get(h->pc_acc, h->pc_n));
-    if (h->ut) CHK(get(h->ut->sus_acc, h->ut->sus_n));
+    const size_t off = red_nsum(h) - RED_STAT_SUMS;
     double tail[RED_STAT_SUMS + 4];
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(tail, h->red_buf + off, sizeof(tail), hipMemcpyDeviceToHost));
@@ -1576,6 +1575,23 @@ int dqmc_reduce_import(dqmc_handle *h, const double *host_in)
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(h->red_buf, host_in, (red_nsum(h) + 4) * sizeof(double), hipMemcpyHostToDevice));
     CHK(red_unpack(h));
+    return DQMC_OK;
+}
+// section `which` of the last reduction: 0 Green's-function sums (dqmc_accumulator_size doubles), 1 correlations,
+// 2 pairing, 3 susceptibilities (sizes as the local getters report)
+int dqmc_get_reduced(dqmc_handle *h, int32_t which, double *host_out)
+{
+    ENTER(h);
+    if (!host_out || which < 0 || which > 3) return fail(h, DQMC_ERR_INVALID, "dqmc_get_reduced: bad arguments");
+    if (!h->red_valid) return fail(h, DQMC_ERR_STATE, "call dqmc_reduce first");
+    const size_t sizes[4] = {h->acc_n, h->corr_n, h->pc_n, h->ut ? h->ut->sus_n : 0};
+    size_t off = 0;
+    for (int i = 0; i < which; ++i) off += sizes[i];
+    if (sizes[which] == 0) return fail(h, DQMC_ERR_STATE, "dqmc_get_reduced: this accumulator is not configured");
+    if (red_nsum(h) != sizes[0] + sizes[1] + sizes[2] + sizes[3] + RED_STAT_SUMS || h->red_cap < red_nsum(h) + 4)
+        return fail(h, DQMC_ERR_STATE, "accumulators were reconfigured after the last reduction");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(host_out, h->red_buf + off, sizes[which] * sizeof(double), hipMemcpyDeviceToHost));
     return DQMC_OK;
 }
 int dqmc_get_reduced_stats(dqmc_handle *h, dqmc_stats *out)

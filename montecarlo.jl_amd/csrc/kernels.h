@@ -105,6 +105,11 @@ struct QrCoopWorkspace {
     unsigned long long epoch = 0;
     int max_blocks = 0;   // launch the cooperative kernel only if its grid fits (co-residency)
     int tail_j0 = 128;    // n == 256: hand-over step to qr_tail_kernel (0 = cooperative kernel only; 64, 96, 128)
+    // A/B and test switches, read from the environment when the workspace is set up (per handle / per primitive call):
+    int force_sc1 = 0;      // DQMC_QR_SC1: write-through (agent-scope) packet stores regardless of placement
+    int no_coop = 0;        // DQMC_QR_NOCOOP: single-workgroup kernels only
+    int force_timeout = 0;  // DQMC_QR_FORCE_TIMEOUT: 1 = every cooperative launch gives up at once;
+                            // "step:<j>" -> 2 + j: part 3 of every matrix stops publishing at step j (bounded spins run out)
 };
 // ws may be null: single-workgroup kernels only
 // W (n_units x strideW, may be null): output of the cooperative kernel, which leaves A intact so that a time-out of

@@ -687,7 +687,7 @@ __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double
     if (unit >= n_units) return;  // all parts of a missing unit leave together
     // The factored matrix goes to W, the input A is only read: a hand-off time-out therefore leaves the input intact
     // and the guarded single-workgroup kernel launched behind this one redoes the factorisation (fb[0] = epoch).
-    if (force_timeout) {  // test hook (DQMC_QR_FORCE_TIMEOUT): behave like a launch whose hand-offs timed out
+    if (force_timeout == 1) {  // test hook (DQMC_QR_FORCE_TIMEOUT=1): behave like a launch whose hand-offs timed out
         if (threadIdx.x == 0) atomicExch(&fb[0], (int)(epoch & 0x7fffffffull));
         return;
     }
@@ -736,6 +736,10 @@ __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double
     if (force_sc1) same_xcd = false;
 
     for (int j = 0; j < nsteps; ++j) {
+        // test hook (DQMC_QR_FORCE_TIMEOUT=step:<j>): part 3 drops out of the hand-off at step j, as a workgroup that
+        // lost its CU would; the other parts run into the bounded spins, raise fb[0] and leave the input to the
+        // guarded kernel behind this launch
+        if (force_timeout >= 2 && part == 3 && j == force_timeout - 2) return;
         const int par = j & 1;
         const unsigned tag = (unsigned)(epoch * 1024ull + (unsigned long long)j + 1ull);
         // the column now at position j: read here, three barriers before thread 0 rewrites the table
@@ -1366,7 +1370,7 @@ static hipError_t launch_qr_single(int n, int n_units, double *A, long strideA, 
                                    const double *src, long strideSrc, int *guard, int guard_val, hipStream_t s,
                                    double *X = nullptr, long strideX = 0, const int *never = nullptr)
 {
-    static const bool no_tile = getenv("DQMC_QR_STREAM") != nullptr;
+    const bool no_tile = getenv("DQMC_QR_STREAM") != nullptr;  // (A/B switches are read per launch: the tests toggle them)
     if (n > 128 && n <= 256 && !no_tile) {
         const size_t lds_t = (64 * QT_LSTRIDE + 3 * 256 + 8 * QT_VS + 8 * 256) * sizeof(double) + 256 * sizeof(int);
         int dev = 0;
@@ -1408,17 +1412,15 @@ hipError_t launch_qr_pivot(int n, int n_units, double *A, long strideA, double *
 {
     if (n > 1024) return hipErrorInvalidValue;
     *factored = A;
-    static const bool no_coop = getenv("DQMC_QR_NOCOOP") != nullptr;
     // cooperative kernel: all 8 workgroups of every unit must be co-resident (they wait for each other); the grid is
     // admitted only if it fits the occupancy the runtime reports for this kernel.  Should another stream hold CUs
     // for longer than the bounded spins allow, the launch gives up and the guarded kernel behind it takes over.
-    if (ws && ws->mailbox && W && n <= 256 && !no_coop) {
+    if (ws && ws->mailbox && W && n <= 256 && !ws->no_coop) {
         const int groups = (n_units + 7) / 8;
         const int blocks = groups * 8 * QC_PARTS;
         if (blocks <= ws->max_blocks) {
             ws->epoch += 1;
-            static const int force_sc1 = getenv("DQMC_QR_SC1") != nullptr;  // write-through packets regardless of placement
-            static const int force_to = getenv("DQMC_QR_FORCE_TIMEOUT") != nullptr;
+            const int force_sc1 = ws->force_sc1, force_to = ws->force_timeout;
             // n == 256: the first steps cooperatively, the rest on one CU per matrix (qr_tail_kernel)
             const int tail_j0 = ws->tail_j0;  // DQMC_QR_TAIL at handle creation; default 128 x 128 tail
             const bool two_phase = n == 256 && X && (tail_j0 == 64 || tail_j0 == 96 || tail_j0 == 128);
@@ -1451,26 +1453,41 @@ hipError_t launch_qr_pivot(int n, int n_units, double *A, long strideA, double *
                             tail_ok ? ws->fb : nullptr);
 }
 
+// D = |diag R| (UDT.jl:268-272) for every unit
+__global__ __launch_bounds__(256) void udt_diag_kernel(int n, int n_units, const double *__restrict__ Fall, long strideF,
+                                                      double *__restrict__ Dall, long strideD)
+{
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)n_units * n) return;
+    const int unit = (int)(idx / n), i = (int)(idx - (long)unit * n);
+    Dall[(long)unit * strideD + i] = fabs(Fall[(long)unit * strideF + i + (long)n * i]);
+}
+
 // D, V and T from the factored matrix (UDT.jl:268-306).  One workgroup per unit.
 constexpr int UF_SPLIT = 8;  // workgroups per matrix (column slabs): 32 matrices alone would leave 7/8 of the chip idle
-__global__ __launch_bounds__(256) void udt_finish_kernel(int n, double *__restrict__ Aall, long strideA,
-                                                        const double *__restrict__ Fall, long strideF,
+__global__ __launch_bounds__(256) void udt_finish_kernel(int n, double *Aall, long strideA,
+                                                        const double *Fall, long strideF,
                                                         const int *__restrict__ pivall,
                                                         double *__restrict__ Dall, long strideD,
                                                         double *__restrict__ Vall, long strideV,
-                                                        double *__restrict__ Tall, long strideT, int apply_pivot)
+                                                        double *__restrict__ Tall, long strideT, int apply_pivot,
+                                                        int d_ready)
 {
     extern __shared__ __attribute__((aligned(16))) double dinv[];  // 1/D
     const int unit = blockIdx.x / UF_SPLIT, slab = blockIdx.x % UF_SPLIT;
-    double *__restrict__ A = Aall + (long)unit * strideA;
-    const double *__restrict__ F = Fall + (long)unit * strideF;  // the factored matrix (may be A itself)
+    double *A = Aall + (long)unit * strideA;
+    const double *F = Fall + (long)unit * strideF;  // the factored matrix (may be A itself: no __restrict__)
     double *__restrict__ D = Dall + (long)unit * strideD;
     const int *__restrict__ piv = pivall + (long)unit * n;
     double *__restrict__ V = Vall ? Vall + (long)unit * strideV : nullptr;
     double *__restrict__ T = Tall ? Tall + (long)unit * strideT : nullptr;
+    // d_ready: D was taken from the diagonal by udt_diag_kernel in a launch of its own.  That form is mandatory when
+    // this kernel rescales the factored matrix IN PLACE (F == A, apply_pivot == 0): the diagonal entry (i, i) is
+    // rewritten to +-1 by the workgroup that owns column i, and a workgroup of the same matrix that starts later
+    // would otherwise read |+-1| instead of D[i] (the wrong Green's function of gpurun_out/r02_t3.log)
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const double d = fabs(F[i + (long)n * i]);
-        if (slab == 0) D[i] = d;
+        const double d = d_ready ? D[i] : fabs(F[i + (long)n * i]);
+        if (slab == 0 && !d_ready) D[i] = d;
         dinv[i] = 1.0 / d;
     }
     __syncthreads();
@@ -1493,8 +1510,16 @@ hipError_t launch_udt_finish(int n, int n_units, double *A, long strideA, const 
                              const int *pivot, double *D, long strideD, double *V, long strideV, double *Tout,
                              long strideT, int apply_pivot, hipStream_t s)
 {
+    // in-place rescaling (Val(false) behind one of the in-place factorisations): D in a launch of its own, see the kernel
+    const int d_ready = (!apply_pivot && F == A) ? 1 : 0;
+    if (d_ready) {
+        hipLaunchKernelGGL(udt_diag_kernel, dim3((n_units * n + 255) / 256), dim3(256), 0, s, n, n_units, F, strideF, D,
+                           strideD);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(udt_finish_kernel, dim3(n_units * UF_SPLIT), dim3(256), n * sizeof(double), s, n, A, strideA,
-                       F, strideF, pivot, D, strideD, V, strideV, Tout, strideT, apply_pivot);
+                       F, strideF, pivot, D, strideD, V, strideV, Tout, strideT, apply_pivot, d_ready);
     return hipGetLastError();
 }
 
@@ -1730,7 +1755,7 @@ hipError_t launch_trsm_right_upper(int n, int n_units, const double *A, long sA,
                                    const int *pivot, const double *dmul, long sV, double *Out, long sO,
                                    double *winv, hipStream_t s, double *scratch)
 {
-    static const bool no_mfma = getenv("DQMC_TRSM_SIMPLE") != nullptr;
+    const bool no_mfma = getenv("DQMC_TRSM_SIMPLE") != nullptr;
     const size_t lds_m = (256 * TM_XS + 16 * TM_TS + 16 * 18) * sizeof(double);
     auto set_attr = [&]() {
         int dev = 0;
@@ -1747,7 +1772,7 @@ hipError_t launch_trsm_right_upper(int n, int n_units, const double *A, long sA,
         hipLaunchKernelGGL(trsm_diag_inv_kernel, dim3(nblk, n_units), dim3(16), 0, s, n, T, sT, dmul, sV, winv, nblk);
         set_attr();
         // (in place is fine for both kernels: a workgroup reads all entries of its own 32 rows before it writes any)
-        static const bool left_looking = getenv("DQMC_TRSM_LL") != nullptr;  // the slab-in-LDS kernel (A/B measurements)
+        const bool left_looking = getenv("DQMC_TRSM_LL") != nullptr;  // the slab-in-LDS kernel (A/B measurements)
         if (left_looking)
             hipLaunchKernelGGL(trsm_mfma_kernel, dim3(n_units * slabs), dim3(128), lds_m, s, n, n, 0, n, nblk, A, sA, T, sT,
                                pivot, dmul, sV, Out, sO, slabs, winv);

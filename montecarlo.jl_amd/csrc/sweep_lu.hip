@@ -812,7 +812,7 @@ hipError_t launch_sweep_lu(int n, int nb, int n_walkers, const double *G, long s
 {
     if (nsites < 1 || nsites > 64 || site0 < 0 || site0 + nsites > n || nb < 1 || nb > 2) return hipErrorInvalidValue;
     const bool full = nsites == 64;
-    static const bool one_wave = getenv("DQMC_SWEEP_LU1") != nullptr;  // single-wave elimination (A/B measurements)
+    const bool one_wave = getenv("DQMC_SWEEP_LU1") != nullptr;  // single-wave elimination (A/B measurements)
     if (one_wave) {
         dim3 grid(n_walkers), block(64);
 #define LU_LAUNCH(NBV, FL)                                                                                        \

@@ -442,6 +442,18 @@ class DQMC:
         statistics) over all ranks of `comm` (a sharding.Communicator, or None for this handle alone)"""
         self._c(lib().dqmc_reduce(self._h, comm.handle if comm is not None else None))
 
+    def reduced(self, which="greens"):
+        """dqmc_get_reduced: the global sums of the last reduction (the handle's own accumulators keep the local sums);
+        `which` = greens | correlations | pairing | susceptibilities, layouts as the local getters"""
+        idx = {"greens": 0, "correlations": 1, "pairing": 2, "susceptibilities": 3}[which]
+        n = C.c_size_t()
+        size_fn = (lib().dqmc_accumulator_size, lib().dqmc_correlations_size, lib().dqmc_pairing_size,
+                   lib().dqmc_susceptibilities_size)[idx]
+        self._c(size_fn(self._h, C.byref(n)))
+        out = np.zeros(n.value)
+        self._c(lib().dqmc_get_reduced(self._h, idx, dptr(out)))
+        return out
+
     def reduced_analysis(self):
         st = _lib.Stats()
         self._c(lib().dqmc_get_reduced_stats(self._h, C.byref(st)))

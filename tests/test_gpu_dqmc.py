@@ -238,13 +238,20 @@ def test_cooperative_qr_timeout_falls_back(gpu, O):
 
 
 @pytest.mark.parametrize("plain", [{"DQMC_NO_SLAB": "1"}, {"DQMC_SWEEP_SPLIT": "1"}, {"DQMC_QR_TAIL": "0"},
-                                   {"DQMC_SWEEP_SPLIT": "1", "DQMC_FLUSH_NCP2": "1"}],
-                         ids=["slab_chains", "fused_sweep", "two_phase_qr", "two_pass_flush"])
+                                   {"DQMC_SWEEP_SPLIT": "1", "DQMC_FLUSH_NCP2": "1"}, {"DQMC_QR_SC1": "1"},
+                                   {"DQMC_QR_NOCOOP": "1"}, {"DQMC_QR_NOCOOP": "1", "DQMC_QR_TAIL": "0"},
+                                   {"DQMC_TRSM_LL": "1"}, {"DQMC_TRSM_SIMPLE": "1"}, {"DQMC_SWEEP_OLD": "1"},
+                                   {"DQMC_SWEEP_LU1": "1", "DQMC_SWEEP_SPLIT": "1"}],
+                         ids=["slab_chains", "fused_sweep", "two_phase_qr", "two_pass_flush", "qr_sc1_mailbox",
+                              "qr_tile_plus_tail", "qr_tile_only", "trsm_left_looking", "trsm_substitution",
+                              "sweep_round1", "sweep_one_wave"])
 def test_fast_paths_against_their_plain_forms(gpu, plain):
-    """The round-2 launch forms at n = 256 (slab-resident product chains, elimination fused with the previous chunk's
+    """The default launch forms at n = 256 (slab-resident product chains, elimination fused with the previous chunk's
     flush, two-phase QR; the two-pass flush of the throughput regime against the one-pass one) against the forms they
     replace, selected per handle / per launch through the environment: same seeds, HS field identical, G within the
-    parity tolerance (the forms differ by reassociation only)."""
+    parity tolerance (the forms differ by reassociation only).  qr_sc1_mailbox is the cooperative QR with agent-scope
+    (write-through) packet stores, i.e. the form that stays inside the HIP memory model; the remaining entries are the
+    fallbacks that ship behind switches (single-workgroup QR kernels, round-1 TRSM and sweep kernels)."""
     def run(env):
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)

@@ -14,15 +14,19 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _measure(mc, sweeps):
+    for _ in range(sweeps):
+        mc.update_until_measure()
+        mc.accumulate_greens()
+        mc.accumulate_correlations()
+
+
 def _run(gpu, first, W, model_cls=None, L=4, beta=2.0, sweeps=3):
     model = (model_cls or gpu.HubbardModelRepulsive)(L, 2)
     mc = gpu.DQMC(model, beta=beta, n_walkers=W, seed=123, first_walker=first)
     mc.set_pair_directions(gpu.EachSitePairByDistance(model.l))
     mc.prepare()
-    for _ in range(sweeps):
-        mc.update_until_measure()
-        mc.accumulate_greens()
-        mc.accumulate_correlations()
+    _measure(mc, sweeps)
     return mc
 
 
@@ -44,13 +48,30 @@ def test_sharded_handles_equal_one_big_handle(gpu):
     ref = big.reduce_export()
     comb = _combine([a.reduce_export(), b.reduce_export()])
     assert np.allclose(comb, ref, rtol=1e-12, atol=1e-12)
-    # import the combined buffer into one shard: its accumulators and counters are now the global ones
+    # import the combined buffer into one shard: dqmc_get_reduced / dqmc_get_reduced_stats give the global sums, the
+    # shard's own accumulators keep its local sums
+    local = a.accumulators().copy()
     a.reduce_import(comb)
-    assert np.allclose(a.accumulators(), big.accumulators(), rtol=1e-12, atol=1e-12)
-    assert np.allclose(a.correlations_raw(), big.correlations_raw(), rtol=1e-12, atol=1e-12)
+    assert np.allclose(a.reduced("greens"), big.accumulators(), rtol=1e-12, atol=1e-12)
+    assert np.allclose(a.reduced("correlations"), big.correlations_raw(), rtol=1e-12, atol=1e-12)
+    assert np.array_equal(a.accumulators(), local)
     ra = a.reduced_analysis()
     tot = big.analysis_sum()
     assert (ra.prop_local, ra.acc_local) == tot
+    # the reduction is repeated every measure_rate sweeps (DQMC.jl:429-436): a SECOND reduction after more samples
+    # must again equal the big handle (writing the global sums back into the shards would count the first three
+    # samples twice here)
+    for m in (big, a, b):
+        _measure(m, 2)
+    comb2 = _combine([a.reduce_export(), b.reduce_export()])
+    assert np.allclose(comb2, big.reduce_export(), rtol=1e-12, atol=1e-12)
+    for m in (a, b):
+        m.reduce_import(comb2)
+        assert np.allclose(m.reduced("greens"), big.accumulators(), rtol=1e-12, atol=1e-12)
+        assert np.allclose(m.reduced("correlations"), big.correlations_raw(), rtol=1e-12, atol=1e-12)
+        assert m.reduced("greens")[-1] == 5 * 2 * W
+        ra = m.reduced_analysis()
+        assert (ra.prop_local, ra.acc_local) == big.analysis_sum()
     for m in (big, a, b):
         m.close()
 
@@ -69,10 +90,14 @@ def test_rccl_single_rank_reduce(gpu):
         handle = comm
     mc.reduce(Cm)
     assert np.array_equal(mc.accumulators(), before)
+    assert np.array_equal(mc.reduced("greens"), before)
     ra = mc.reduced_analysis()
     assert (ra.prop_local, ra.acc_local) == mc.analysis_sum()
+    mc.reduce(Cm)  # again, nothing accumulated in between: same sums (not doubled)
+    assert np.array_equal(mc.reduced("greens"), before)
     mc.reduce(None)
     assert np.array_equal(mc.accumulators(), before)
+    assert np.array_equal(mc.reduced("correlations"), mc.correlations_raw())
     mc.close()
     gpu._lib.check(L.dqmc_comm_destroy(comm))
 
@@ -88,8 +113,10 @@ def _worker(rank, world, port, W, ret):
     lo, hi = gpu.walker_block(rank, world, world * W)
     mc = _run(gpu, lo, hi - lo)
     mc.reduce_host(dist)
+    _measure(mc, 1)
+    mc.reduce_host(dist)  # second reduction of the same run (3 + 1 samples per walker)
     ra = mc.reduced_analysis()
-    ret[rank] = (mc.accumulators(), mc.correlations_raw(), (ra.prop_local, ra.acc_local),
+    ret[rank] = (mc.reduced("greens"), mc.reduced("correlations"), (ra.prop_local, ra.acc_local),
                  [mc.conf(w) for w in range(hi - lo)])
     mc.close()
     dist.barrier()
@@ -103,7 +130,7 @@ def test_two_processes_one_device(gpu):
     ret = mgr.dict()
     port = 29600 + (os.getpid() % 2000)
     mp.spawn(_worker, args=(world, port, W, ret), nprocs=world, join=True)
-    big = _run(gpu, 0, world * W)
+    big = _run(gpu, 0, world * W, sweeps=4)
     for rank in range(world):
         acc, corr, cnt, confs = ret[rank]
         assert np.allclose(acc, big.accumulators(), rtol=1e-12, atol=1e-12)
