@@ -149,6 +149,19 @@ def main():
     steps = args.steps if args.steps is not None else cfg["steps"]
     warmup = args.warmup if args.warmup is not None else cfg["warmup"]
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # bare `bench.py --gpus N` (no launcher): start N fresh ranks, one per GPU, BEFORE anything in this process
+        # touches the GPU (this parent never does), and pass rank 0's JSON line through
+        import subprocess
+        port = 29500 + os.getpid() % 2000
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        p = subprocess.run(cmd, stdout=subprocess.PIPE)
+        lines = [ln for ln in p.stdout.decode(errors="replace").splitlines() if ln.startswith('{"metric"')]
+        if lines:
+            print(lines[-1], flush=True)
+        sys.exit(p.returncode if p.returncode else (0 if lines else 1))
+
     # stdout must carry exactly ONE JSON line: native libraries (the RCCL banner, HIP warnings) write
     # to fd 1 as well, so fd 1 is pointed at stderr for the run and the JSON goes to the saved fd
     sys.stdout.flush()
@@ -158,14 +171,24 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     n_gpus = max(world, 1)
+    if args.gpus != n_gpus and "WORLD_SIZE" in os.environ and rank == 0:
+        print("bench.py: --gpus %d ignored, the launcher started %d rank(s)" % (args.gpus, n_gpus), file=sys.stderr)
+    # BENCH_ONE_DEVICE: rehearsal of the N-rank path on a one-GPU box - every rank uses device 0, the process group is
+    # gloo and the measurement reduction goes through the host-mediated export / import pair (RCCL needs one device
+    # per rank); the JSON has the N-rank shape, the number means nothing
+    one_dev = bool(os.environ.get("BENCH_ONE_DEVICE"))
+    dev = 0 if one_dev else local_rank
     import torch
     dist = None
     if world > 1 or os.environ.get("BENCH_FORCE_DIST"):  # the env var exercises the RCCL path on one rank
         for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533")):
             os.environ.setdefault(k, v)  # torchrun sets these; a bare single-rank rehearsal does not
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev)
+        if one_dev:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
 
     import __graft_entry__ as g
     mc_amd = g.load_package()
@@ -182,7 +205,7 @@ def main():
     Model = mc_amd.HubbardModelAttractive if cfg["model"] == "attractive" else mc_amd.HubbardModelRepulsive
     model = Model(cfg["L"], 2)
     mc = mc_amd.DQMC(model, beta=cfg["beta"], delta_tau=cfg["dtau"], safe_mult=SAFE_MULT, n_walkers=walkers,
-                     device_id=local_rank, seed=BASE_SEED, first_walker=first)
+                     device_id=dev, seed=BASE_SEED, first_walker=first)
     n, M = mc.N, mc.p.slices
     K, nb = M // SAFE_MULT, (2 if cfg["model"] == "repulsive" else 1)
     mc.prepare()
@@ -191,17 +214,21 @@ def main():
     # so that the run still completes; which path ran is reported in config.reduction.
     comm, reduction = None, "none (single rank)"
     acc_dev = None
-    if dist is not None:
+    if dist is not None and one_dev:
+        reduction = "dqmc_reduce_export -> gloo all_reduce -> dqmc_reduce_import (BENCH_ONE_DEVICE rehearsal)"
+    elif dist is not None:
         try:
-            comm = mc_amd.Communicator(dist, device_id=local_rank)
+            comm = mc_amd.Communicator(dist, device_id=dev)
             reduction = "dqmc_reduce (ncclAllReduce inside libdqmc_hip.so)"
         except Exception as e:  # noqa: BLE001
             comm = None
-            acc_dev = torch.zeros(mc.accumulator_size(), dtype=torch.float64, device="cuda:%d" % local_rank)
+            acc_dev = torch.zeros(mc.accumulator_size(), dtype=torch.float64, device="cuda:%d" % dev)
             reduction = "torch.distributed all_reduce of the exported accumulators (library communicator failed: %s)" % e
 
     def reduce_measurements():
-        if acc_dev is not None:
+        if one_dev and dist is not None:
+            mc.reduce_host(dist)
+        elif acc_dev is not None:
             mc.export_accumulators(acc_dev.data_ptr())
             mc_amd.reduce_accumulators(acc_dev, dist)
         else:
@@ -226,7 +253,7 @@ def main():
     dt = time.perf_counter() - t0
     a1 = mc.analysis_sum()
     if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda:%d" % local_rank)
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if one_dev else "cuda:%d" % dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     # Kernel pass: the same K steps once more with HIP events attached to every launch (drained after its own timer
@@ -243,6 +270,7 @@ def main():
         tim = mc.timing()
         mc.timing_enable(False)
     acc_rate = (a1[1] - a0[1]) / max(1, a1[0] - a0[0])
+    qr_fallbacks = mc.qr_fallbacks()
 
     value = total_walkers * steps / dt
     ms_per_step = dt / steps * 1e3
@@ -259,9 +287,35 @@ def main():
               "8 workgroups per matrix) + qr_tail_kernel (steps 128..255 on one CU per matrix)",
         "trsm": "rdivp! and the compact-WY triangle (blocked substitution, MFMA)",
         "sweep": "sweep_lu4_kernel / sweep_fused_kernel: Metropolis decisions = conditional elimination of G[c,c] "
-                 "(sequential site chain), fused with the flush of the previous chunk when the grid is co-resident",
+                 "(sequential site chain), fused with the flush of the previous chunk when the grid is co-resident; "
+                 "its flops are the rank-1 updates applied inside the fused launches",
         "misc": "udt_finish, copies, propagation-error check",
     }
+    # rank-1 flops by where they are applied: of the 2M * ceil(N/64) chunk flushes per sweep the `flush` family runs
+    # only the stand-alone launches (the last chunk of every slice when the fused form is active); the others happen
+    # inside sweep_fused_kernel and are credited to `sweep`
+    if tim:
+        chunks = 2.0 * M * ((n + 63) // 64) * steps
+        share = min(1.0, tim.get("flush", (0.0, 0))[1] / chunks) if chunks else 1.0
+        F["sweep"] = F["flush"] * (1.0 - share)
+        F["flush"] = F["flush"] * share
+    pmc = {}
+    try:  # PMC passes cannot run inside this process: committed rocprofv3 --pmc summary of the same workload
+        import glob
+        pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+        if pm and args.config == 3 and walkers == 32:
+            pmc = json.load(open(pm[-1]))
+            pmc["_file"] = os.path.basename(pm[-1])
+    except Exception:
+        pmc = {}
+
+    def pmc_sum(prefixes, counter):
+        tot, hit = 0.0, False
+        for k, v in pmc.items():
+            if isinstance(v, dict) and any(k.startswith(q) for q in prefixes) and counter in v:
+                tot += v[counter]["mean_per_launch"]
+                hit = True
+        return tot if hit else None
     kernels = []
     sum_ms = 0.0
     for fam, (ms, launches) in sorted(tim.items(), key=lambda kv: -kv[1][0]):
@@ -279,13 +333,30 @@ def main():
             hb = 16.0 * n * n * walkers * nb * launches  # read + write of G per launch
             ent["algorithmic_GBps"] = hb / (ms * 1e-3) / 1e9
             ent["frac_of_hbm_peak"] = ent["algorithmic_GBps"] / HBM_PEAK_GBS
+        if fam == "qr" and ms > 0:
+            # north_star: achieved HBM GB/s on the QR panels.  SURVEY 8(d): 24 n^2 + 8 n bytes per UDT (read A; write
+            # U, T, D); one "launch" of this family = one batched factorisation of all units
+            hb = (24.0 * n * n + 8.0 * n) * walkers * nb * launches
+            ent["algorithmic_GBps"] = hb / (ms * 1e-3) / 1e9
+            ent["frac_of_hbm_peak"] = ent["algorithmic_GBps"] / HBM_PEAK_GBS
+            fe, wr = pmc_sum(("qr_coop", "qr_tail"), "FETCH_SIZE"), pmc_sum(("qr_coop", "qr_tail"), "WRITE_SIZE")
+            if fe is not None and wr is not None:  # KB per launch; gfx950 FETCH_SIZE x2 correction as an upper bound
+                ent["pmc_hbm_bytes_per_batch"] = (2.0 * fe + wr) * 1024.0
+                ent["pmc_GBps"] = ent["pmc_hbm_bytes_per_batch"] / (ms * 1e-3 / launches) / 1e9
+                ent["pmc_frac_of_hbm_peak"] = ent["pmc_GBps"] / HBM_PEAK_GBS
+                ent["pmc_source"] = pmc.get("_file")
+        if fam == "gemm" and pmc:
+            busy, cyc = pmc_sum(("slab_chain",), "SQ_VALU_MFMA_BUSY_CYCLES"), pmc_sum(("slab_chain",), "SQ_BUSY_CYCLES")
+            if busy and cyc:  # MFMA-pipe busy cycles per SIMD-busy cycle (both summed over the chip), slab kernel
+                ent["mfma_busy_frac"] = busy / (4.0 * cyc)
+                ent["pmc_source"] = pmc.get("_file")
         kernels.append(ent)
     # HBM-side traffic of one full GEMM launch: PMC passes cannot run inside this process; the number comes from the
     # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE profile (gfx950 x2 FETCH correction applied there)
     traffic = None
     try:
         import glob
-        pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_gemm.json")))
+        pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_gemm.json")))
         if pm and args.config == 3 and walkers == 32:
             traffic = json.load(open(pm[-1]))["traffic_bytes_per_launch"]
     except Exception:
@@ -299,7 +370,11 @@ def main():
         "config": {"workload": "%s, %d walkers per MI355X" % (cfg["name"], walkers), "config": args.config,
                    "walkers_per_gpu": walkers, "total_walkers": total_walkers,
                    "parallelism": "walkers sharded, %d rank(s)" % n_gpus, "acceptance_rate": acc_rate,
-                   "reduction": reduction},
+                   "reduction": reduction,
+                   # a cooperative-QR launch that timed out and was redone by the guarded kernel is a FAULT of the fast
+                   # path, not a slow run: must be 0 (device_errors: the sweep kernels' bounded waits, checked at every
+                   # synchronisation - a non-zero word would have raised before this line)
+                   "qr_fallbacks": qr_fallbacks, "device_errors": 0},
         "roofline": {"bound": "mfma", "achieved": whole_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": whole_tflops / FP64_PEAK_TFLOPS,
                      "definition": "SURVEY 8(d): algorithmic flops of the reference algorithm per walker-sweep "
@@ -312,7 +387,8 @@ def main():
                                          "the same K steps; ms_per_step / value come from the event-free region",
                      "dominant_kernel": None if dom is None else {k: dom.get(k) for k in (
                          "family", "avg_launch_us", "launches_per_sweep", "bound", "achieved_tflops",
-                         "frac_of_fp64_peak")}},
+                         "frac_of_fp64_peak", "algorithmic_GBps", "frac_of_hbm_peak", "pmc_GBps",
+                         "pmc_frac_of_hbm_peak")}},
     }
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         import subprocess

@@ -48,16 +48,39 @@ struct dqmc_handle {
     std::vector<double *> su, sd, st;
     double *Ul = nullptr, *Ur = nullptr, *Tl = nullptr, *Tr = nullptr, *greens = nullptr, *greens_temp = nullptr;
     double *tmp1 = nullptr, *tmp2 = nullptr, *bufA = nullptr, *bufB = nullptr;
-    double *qrV = nullptr, *qrW = nullptr, *qrS = nullptr;
-    double *trsm_w = nullptr;  // inverted 16 x 16 diagonal blocks (launch_trsm_right_upper)
-    double *trsm_s = nullptr;  // n > 256: gathered / panel-solved copy of the right-hand side
-    double *Dl = nullptr, *Dr = nullptr, *tau = nullptr;
-    int *pivot = nullptr;
+    // scratch of one UDT (udt_AVX_pivot!): V (Householder vectors; hand-over buffer of the two-phase QR before that),
+    // W (factored matrix of the cooperative QR, then the compact-WY product), S (V'V), tau, pivot, and what the
+    // triangular solves need (winv: inverted 16 x 16 diagonal blocks; ts: n > 256, panel-solved copy of the right-hand
+    // side).  Two sets, so that the Q formation of one decomposition can run on the auxiliary stream while the next
+    // factorisation already runs on the main one; the auxiliary stream has solve scratch of its own (aux_winv / aux_ts).
+    struct QrSet {
+        double *V = nullptr, *W = nullptr, *S = nullptr, *tau = nullptr, *winv = nullptr, *ts = nullptr;
+        int *pivot = nullptr;
+    } qs[2];
+    double *aux_winv = nullptr, *aux_ts = nullptr;
+    double *&qrV = qs[0].V, *&qrW = qs[0].W, *&qrS = qs[0].S, *&trsm_w = qs[0].winv, *&trsm_s = qs[0].ts, *&tau = qs[0].tau;
+    int *&pivot = qs[0].pivot;
+    double *Dl = nullptr, *Dr = nullptr;
+    // Independent kernels of one stabilisation step run side by side (stack.jl:519-550, 585-614 have no such notion:
+    // one thread): `cur` is the stream the launch helpers use (stream, or aux inside a forked region).
+    hipStream_t aux = nullptr, cur = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool overlap = false, aux_pending = false;
+    bool overlap_rdivp = false;  // DQMC_OVERLAP_RDIVP: rdivp! next to the Q formation before it (two 120 KB-LDS TRSM kernels
+                                 // cannot share a CU: measured no gain, off by default)
+    // slice-matrix chain of the NEXT stack interval, advanced by one product after every sweep_spatial (aux stream)
+    struct {
+        bool valid = false;
+        int dir = 0, idx = 0, next_t = 0;   // products 0 .. next_t - 1 of interval idx are done
+        double *buf[2] = {nullptr, nullptr};
+        double *out = nullptr;
+    } chain;
     double *sU = nullptr, *sVT = nullptr;
     double *greens_alt = nullptr, *lu_img = nullptr;  // decide / apply sweep (sweep_lu.hip)
     bool sweep_lu = true, sweep_fused = true;
     WalkerRng *rng = nullptr;
     DevStats *stats = nullptr;
+    unsigned long long *pc_scratch = nullptr;  // prop_check_kernel: partial maximum + arrival counter per walker
     std::vector<double *> uniforms;  // per walker device arrays
     double *acc = nullptr;
     size_t acc_n = 0;
@@ -164,12 +187,12 @@ struct Timed {
         };
         a = get();
         b = get();
-        (void)hipEventRecord(a, h->stream);
+        (void)hipEventRecord(a, h->cur);
     }
     ~Timed()
     {
         if (!h->timing) return;
-        (void)hipEventRecord(b, h->stream);
+        (void)hipEventRecord(b, h->cur);
         h->pending.push_back({a, b, fam});
         if (h->pending.size() >= 2048) (void)timing_drain(h);
     }
@@ -222,7 +245,7 @@ static int timing_push(dqmc_handle *h, hipEvent_t a, hipEvent_t b, int fam)
 static int run_gemm(dqmc_handle *h, const GemmArgs &g)
 {
     if (!h->timing) {
-        HIPCHK(launch_gemm(g, h->stream));
+        HIPCHK(launch_gemm(g, h->cur));
         return 0;
     }
     // kernel-only duration: the events are attached to the dispatch itself (no launch gap inside)
@@ -233,7 +256,7 @@ static int run_gemm(dqmc_handle *h, const GemmArgs &g)
         return e;
     };
     hipEvent_t a = get(), b = get();
-    HIPCHK(launch_gemm(g, h->stream, a, b));
+    HIPCHK(launch_gemm(g, h->cur, a, b));
     h->pending.push_back({a, b, DQMC_K_GEMM});
     if (h->pending.size() >= 2048) CHK(timing_drain(h));
     return 0;
@@ -265,25 +288,25 @@ static void slot_swap_spare(dqmc_handle *h, int i)
 static int copy_mat(dqmc_handle *h, double *dst, const double *src)
 {
     Timed t(h, DQMC_K_MISC);
-    HIPCHK(hipMemcpyAsync(dst, src, sizeof(double) * h->units * h->nn, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(dst, src, sizeof(double) * h->units * h->nn, hipMemcpyDeviceToDevice, h->cur));
     return 0;
 }
 static int copy_vec(dqmc_handle *h, double *dst, const double *src)
 {
     Timed t(h, DQMC_K_MISC);
-    HIPCHK(hipMemcpyAsync(dst, src, sizeof(double) * h->units * h->n, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(dst, src, sizeof(double) * h->units * h->n, hipMemcpyDeviceToDevice, h->cur));
     return 0;
 }
 static int set_identity(dqmc_handle *h, double *A)
 {
     Timed t(h, DQMC_K_MISC);
-    HIPCHK(launch_set_identity(h->n, h->units, A, h->nn, h->stream));
+    HIPCHK(launch_set_identity(h->n, h->units, A, h->nn, h->cur));
     return 0;
 }
 static int set_ones(dqmc_handle *h, double *d)
 {
     Timed t(h, DQMC_K_MISC);
-    HIPCHK(launch_fill(d, (size_t)h->units * h->n, 1.0, h->stream));
+    HIPCHK(launch_fill(d, (size_t)h->units * h->n, 1.0, h->cur));
     return 0;
 }
 
@@ -321,69 +344,121 @@ static int check_qr_workspace(dqmc_handle *h)
     return 0;
 }
 
+// ---- fork / join of the auxiliary stream -----------------------------------------
+// fork: what is launched on h->cur (= aux) until aux_end() runs after everything issued to the main stream so far;
+// join: the main stream waits for everything issued to aux so far.  Without an auxiliary stream (stand-alone
+// primitives, DQMC_NO_OVERLAP) the region simply runs on the main stream, in program order.
+static int aux_begin(dqmc_handle *h)
+{
+    if (!h->overlap) return 0;
+    HIPCHK(hipEventRecord(h->ev_fork, h->stream));
+    HIPCHK(hipStreamWaitEvent(h->aux, h->ev_fork, 0));
+    h->cur = h->aux;
+    return 0;
+}
+static void aux_end(dqmc_handle *h)
+{
+    if (!h->overlap) return;
+    h->cur = h->stream;
+    h->aux_pending = true;
+}
+static int aux_join(dqmc_handle *h)
+{
+    if (!h->overlap || !h->aux_pending) return 0;
+    HIPCHK(hipEventRecord(h->ev_join, h->aux));
+    HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
+    h->aux_pending = false;
+    return 0;
+}
+
 // ---- UDT (udt_AVX_pivot!, src/linalg/UDT.jl:192-306) ---------------------------
-// A is factored in place.  Q is formed in compact-WY form with GEMMs instead of the
-// reference's reflector-by-reflector back accumulation (UDT.jl:250-266):
+// A is factored (in place, or into q.W by the cooperative kernel).  Q is formed in compact-WY form with GEMMs instead
+// of the reference's reflector-by-reflector back accumulation (UDT.jl:250-266):
 //   Q = H_1...H_n = I - V S^-1 V',  S = striu(V'V) + diag(1/tau)
-static int udt(dqmc_handle *h, double *A, double *Uout, double *Dout, double *Tout, int apply)
+// udt_factor: "QR decomposition" loop + D, T (and V for the second half); udt_formq: U = Q from V, tau of the set.
+typedef dqmc_handle::QrSet QrSet;
+static int udt_factor(dqmc_handle *h, double *A, double *Dout, double *Tout, int apply, QrSet &q)
 {
     const int n = h->n;
-    const double *F = A;  // where the factored matrix ends up (qrW behind the cooperative QR)
+    const double *F = A;  // where the factored matrix ends up (q.W behind the cooperative QR)
     {
         Timed t(h, DQMC_K_QR);
-        // qrV is free until udt_finish writes V: it serves as the hand-over buffer of the two-phase QR
-        HIPCHK(launch_qr_pivot(n, h->units, A, h->nn, h->tau, h->pivot, &h->qr_ws, h->qrW, h->nn, &F, h->stream, h->qrV,
-                               h->nn));
+        // q.V is free until udt_finish writes V: it serves as the hand-over buffer of the two-phase QR
+        HIPCHK(launch_qr_pivot(n, h->units, A, h->nn, q.tau, q.pivot, &h->qr_ws, q.W, h->nn, &F, h->cur, q.V, h->nn));
     }
     {
         Timed t(h, DQMC_K_MISC);
-        HIPCHK(launch_udt_finish(n, h->units, A, h->nn, F, h->nn, h->pivot, Dout, n, h->qrV, h->nn, Tout, h->nn, apply,
-                                 h->stream));
+        HIPCHK(launch_udt_finish(n, h->units, A, h->nn, F, h->nn, q.pivot, Dout, n, q.V, h->nn, Tout, h->nn, apply,
+                                 h->cur));
     }
-    GemmArgs g = gemm_base(h, U_(h, h->qrV), 1, U_(h, h->qrV), 0, h->qrS);
+    return 0;
+}
+static int udt_formq(dqmc_handle *h, double *Uout, QrSet &q, double *winv, double *ts)
+{
+    const int n = h->n;
+    GemmArgs g = gemm_base(h, U_(h, q.V), 1, U_(h, q.V), 0, q.S);
     CHK(run_gemm(h, g));
     {
         Timed t(h, DQMC_K_TRSM);
-        HIPCHK(launch_trsm_right_upper(n, h->units, h->qrV, h->nn, h->qrS, h->nn, nullptr, h->tau, n, h->qrW, h->nn,
-                                       h->trsm_w, h->stream, h->trsm_s));
+        HIPCHK(launch_trsm_right_upper(n, h->units, q.V, h->nn, q.S, h->nn, nullptr, q.tau, n, q.W, h->nn, winv, h->cur, ts));
     }
-    g = gemm_base(h, U_(h, h->qrW), 0, U_(h, h->qrV), 1, Uout);
+    g = gemm_base(h, U_(h, q.W), 0, U_(h, q.V), 1, Uout);
     g.alpha = -1.0;
     g.ident = 1.0;
     CHK(run_gemm(h, g));
     return 0;
 }
-static int rdivp(dqmc_handle *h, double *A, const double *T)
+static int udt(dqmc_handle *h, double *A, double *Uout, double *Dout, double *Tout, int apply)
+{
+    CHK(udt_factor(h, A, Dout, Tout, apply, h->qs[0]));
+    return udt_formq(h, Uout, h->qs[0], h->qs[0].winv, h->qs[0].ts);
+}
+// Out = A[:, pivot of set q] / triu(T) (rdivp!, general.jl:138-166)
+static int rdivp_set(dqmc_handle *h, const double *A, const double *T, double *Out, const QrSet &q, double *winv, double *ts)
 {
     Timed t(h, DQMC_K_TRSM);
-    HIPCHK(launch_trsm_right_upper(h->n, h->units, A, h->nn, T, h->nn, h->pivot, nullptr, 0, A, h->nn, h->trsm_w,
-                                   h->stream, h->trsm_s));
+    HIPCHK(launch_trsm_right_upper(h->n, h->units, A, h->nn, T, h->nn, q.pivot, nullptr, 0, Out, h->nn, winv, h->cur, ts));
     return 0;
+}
+static int rdivp(dqmc_handle *h, double *A, const double *T)
+{
+    return rdivp_set(h, A, T, A, h->qs[0], h->qs[0].winv, h->qs[0].ts);
 }
 
 // ---- calculate_greens_AVX! (stack.jl:337-393) -----------------------------------
 // L = (Ul, Dl, Tl), R = (Ur, Dr, Tr) are only read (they may be stack slots); h->Ul .. h->Tr are the work matrices
 // the reference overwrites its six inputs with.  L / R may also BE those work matrices (each is consumed before the
 // step that overwrites it).
+// Two kernels that do not depend on each other run side by side (overlap mode): each rdivp! next to the Q formation
+// of the decomposition before it.  On entry the Q of L or R may still be in flight on the auxiliary stream
+// (add_slice_sequence_*): it is awaited after the first factorisation, before L.u / R.u are read.
 static int calculate_greens_src(dqmc_handle *h, double *out, Udt L, Udt R)
 {
     const int n = h->n;
+    QrSet &qa = h->overlap ? h->qs[1] : h->qs[0], &qb = h->qs[0];
+    const bool ov = h->overlap && h->overlap_rdivp;
+    double *winv_x = ov ? h->aux_winv : nullptr, *ts_x = ov ? h->aux_ts : nullptr;
     GemmArgs g = gemm_base(h, U_(h, L.t), 0, U_(h, R.t), 1, out);  // :346-348
     g.colscale = vs_arr(R.d, n);
     g.rowscale = vs_arr(L.d, n);
     CHK(run_gemm(h, g));
-    CHK(udt(h, out, h->Tr, h->Dr, nullptr, 0));                        // :349
+    CHK(udt_factor(h, out, h->Dr, nullptr, 0, qa));                    // :349, first half
+    CHK(aux_join(h));                                                  // L.u / R.u of a slot whose Q was still being formed
+    if (ov) CHK(aux_begin(h));                                         // :361 (out of place: Ur = R.u[:, p] / T)
+    CHK(rdivp_set(h, R.u, out, h->Ur, qa, ov ? winv_x : qa.winv, ov ? ts_x : qa.ts));
+    if (ov) aux_end(h);
+    CHK(udt_formq(h, h->Tr, qa, qa.winv, qa.ts));                      // :349, second half
     CHK(run_gemm(h, gemm_base(h, U_(h, L.u), 0, U_(h, h->Tr), 0, h->Tl)));    // :360
-    {                                                                  // :361 (out of place: Ur = R.u[:, p] / T)
-        Timed t(h, DQMC_K_TRSM);
-        HIPCHK(launch_trsm_right_upper(h->n, h->units, R.u, h->nn, out, h->nn, h->pivot, nullptr, 0, h->Ur, h->nn,
-                                       h->trsm_w, h->stream, h->trsm_s));
-    }
+    CHK(aux_join(h));
     g = gemm_base(h, U_(h, h->Tl), 1, U_(h, h->Ur), 0, h->Tr);         // :362 + :368
     g.adddiag = vs_arr(h->Dr, n);
     CHK(run_gemm(h, g));
-    CHK(udt(h, h->Tr, h->Ul, h->Dr, nullptr, 0));                      // :376
-    CHK(rdivp(h, h->Ur, h->Tr));                                       // :377
+    CHK(udt_factor(h, h->Tr, h->Dr, nullptr, 0, qb));                  // :376
+    if (ov) CHK(aux_begin(h));
+    CHK(rdivp_set(h, h->Ur, h->Tr, h->Ur, qb, ov ? winv_x : qb.winv, ov ? ts_x : qb.ts));  // :377
+    if (ov) aux_end(h);
+    CHK(udt_formq(h, h->Ul, qb, qb.winv, qb.ts));
+    CHK(aux_join(h));                                                  // (the next product overwrites Tr = T of :376)
     CHK(run_gemm(h, gemm_base(h, U_(h, h->Tl), 0, U_(h, h->Ul), 0, h->Tr)));  // :378
     g = gemm_base(h, U_(h, h->Ur), 0, U_(h, h->Tr), 1, out);           // :382-391
     g.kscale = vs_inv(h->Dr, n);
@@ -421,7 +496,7 @@ static int cb_mult(dqmc_handle *h, int which, int slice, const double *X, double
     a.qscale = qscale; a.qstride = h->n;
     hipEvent_t ea, eb;
     timing_events(h, &ea, &eb);
-    HIPCHK(launch_cb_apply(a, h->units, h->stream, ea, eb));
+    HIPCHK(launch_cb_apply(a, h->units, h->cur, ea, eb));
     return timing_push(h, ea, eb, DQMC_K_GEMM);
 }
 
@@ -436,7 +511,6 @@ static SlabArgs slab_base(dqmc_handle *h, const double *X0, long x_su, long x_sb
     a.epl = h->epl; a.eml = h->eml;
     return a;
 }
-static const int8_t *conf_slice(dqmc_handle *h, int slice) { return h->conf + (long)(slice - 1) * h->N; }
 static void slab_step_const(dqmc_handle *h, SlabArgs &a, const double *C)  // shared constant, per block
 {
     SlabStep &st = a.st[a.nsteps++];
@@ -453,82 +527,118 @@ static int run_slab(dqmc_handle *h, const SlabArgs &a)
 {
     hipEvent_t ea, eb;
     timing_events(h, &ea, &eb);
-    HIPCHK(launch_slab_chain(a, h->stream, ea, eb));
+    HIPCHK(launch_slab_chain(a, h->cur, ea, eb));
     return timing_push(h, ea, eb, DQMC_K_GEMM);
 }
 
 // ---- slice sequences (stack.jl:272-311, slice_matrices.jl:42-76) -------------------
-static int add_slice_sequence_left(dqmc_handle *h, int idx)  // idx 1-based as in the reference
+// The s products of a stack interval only need the HS field of slices that sweep_spatial has already left behind, in
+// the order the sweep visits them (up pass: B_l X for l = (idx-1)s+1 .. idx s; down pass: B_l' X for l = idx s ..
+// (idx-1)s+1).  In overlap mode every sweep_spatial therefore advances the chain of the current interval by one
+// product on the auxiliary stream (chain_advance), and the stabilisation step only has the last product (with the
+// Diagonal(D) column scaling of stack.jl:281 / :305) left.  Same kernel, same operand order: bit-identical to the
+// s-step launch.  A chain that does not match the interval (first pass after prepare, a slice swept twice, HS field
+// set from outside) is dropped and the interval is multiplied out in one launch as before.
+static const int8_t *conf_slice(dqmc_handle *h, int slice) { return h->conf + (long)(slice - 1) * h->N; }
+static void chain_steps(dqmc_handle *h, SlabArgs &a, int dir, int idx, int t0, int t1)  // products t0 .. t1 - 1
 {
-    const double *X = uslot(h, idx - 1);
-    double *out = nullptr;
-    if (h->slab && !h->cb.on && h->s <= SLAB_MAX_STEPS) {  // the s products B_l X in one launch
-        out = h->bufA;
-        SlabArgs a = slab_base(h, X, h->nn, 0, out);
-        for (int t = 0; t < h->s; ++t) {
+    for (int t = t0; t < t1; ++t) {
+        SlabStep &st = a.st[a.nsteps];
+        if (dir == 1) {
             slab_step_const(h, a, h->eT2);
-            a.st[t].pre_conf = conf_slice(h, (idx - 1) * h->s + 1 + t);
-            a.st[t].pre_sign = +1;
+            st.pre_conf = conf_slice(h, (idx - 1) * h->s + 1 + t);
+            st.pre_sign = +1;
+        } else {  // B_l' X = eV (eT2' X)
+            slab_step_const(h, a, h->eT2T);
+            st.post_conf = conf_slice(h, idx * h->s - t);
+            st.post_sign = +1;
         }
-        a.col_d = dslot(h, idx - 1); a.col_stride = h->n;  // stack.jl:281
-        CHK(run_slab(h, a));
     }
-    else for (int t = 0; t < h->s; ++t) {
-        const int slice = (idx - 1) * h->s + 1 + t;
-        out = (t & 1) ? h->bufB : h->bufA;
-        if (h->cb.on) {
-            CHK(cb_mult(h, CB_LEFT_B, slice, X, out, t == h->s - 1 ? dslot(h, idx - 1) : nullptr));
-            X = out;
-            continue;
-        }
-        GemmArgs g = gemm_base(h, C_(h, h->eT2), 0, U_(h, X), 0, out);
-        g.kscale = vs_conf(h, slice, +1);
-        if (t == h->s - 1) g.colscale = vs_arr(dslot(h, idx - 1), h->n);  // stack.jl:281
-        CHK(run_gemm(h, g));
-        X = out;
-    }
-    const int sp = h->K + 1;  // new factors into the spare, then slot idx <-> spare: the old slot idx stays readable
-    CHK(udt(h, out, uslot(h, sp), dslot(h, sp), h->tmp2, 1));
-    CHK(run_gemm(h, gemm_base(h, U_(h, h->tmp2), 0, U_(h, tslot(h, idx - 1)), 0, tslot(h, sp))));
-    slot_swap_spare(h, idx);
+}
+static bool chain_ahead_ok(dqmc_handle *h)
+{
+    return h->overlap && h->chain.buf[0] && h->slab && !h->cb.on && h->s >= 2 && h->s <= SLAB_MAX_STEPS;
+}
+// called at the end of sweep_spatial at slice l
+static int chain_advance(dqmc_handle *h, int l)
+{
+    auto &c = h->chain;
+    if (!chain_ahead_ok(h) || (h->direction != 1 && h->direction != -1)) { c.valid = false; return 0; }
+    const int dir = h->direction, idx = (l - 1) / h->s + 1;
+    const int t = dir == 1 ? (l - 1) % h->s : idx * h->s - l;
+    if (t == 0) { c.valid = true; c.dir = dir; c.idx = idx; c.next_t = 0; }
+    else if (!(c.valid && c.dir == dir && c.idx == idx && c.next_t == t)) { c.valid = false; return 0; }
+    if (t >= h->s - 1) return 0;  // the last product belongs to the stabilisation step
+    const double *X = t == 0 ? (dir == 1 ? uslot(h, idx - 1) : uslot(h, idx)) : c.out;
+    double *out = c.buf[t & 1];
+    SlabArgs a = slab_base(h, X, h->nn, 0, out);
+    chain_steps(h, a, dir, idx, t, t + 1);
+    CHK(aux_begin(h));
+    const int rc = run_slab(h, a);
+    aux_end(h);
+    CHK(rc);
+    c.out = out;
+    c.next_t = t + 1;
     return 0;
 }
-static int add_slice_sequence_right(dqmc_handle *h, int idx)
+static int wrap_greens_slab(dqmc_handle *h, const double *src, double *dst, int curr_slice, int direction);
+// dir = +1: add_slice_sequence_left(idx), reads slot idx - 1, writes slot idx; dir = -1: add_slice_sequence_right(idx),
+// reads slot idx, writes slot idx - 1 (idx 1-based as in the reference).  wrap_temp: the up pass's wrap of the old
+// Green's function for the propagation check (stack.jl:534-536) rides on the auxiliary stream.
+static int add_slice_sequence(dqmc_handle *h, int dir, int idx, bool wrap_temp)
 {
-    const double *X = uslot(h, idx);
+    const int src = dir == 1 ? idx - 1 : idx, dst = dir == 1 ? idx : idx - 1;
+    CHK(aux_join(h));  // chain products of this interval; a Q still being formed for the slot read below
+    auto &c = h->chain;
+    int t0 = 0;
+    const double *X = uslot(h, src);
+    if (c.valid && chain_ahead_ok(h) && c.dir == dir && c.idx == idx && c.next_t >= 1) { X = c.out; t0 = c.next_t; }
+    c.valid = false;
+    if (wrap_temp) {
+        if (h->slab && !h->cb.on) {
+            CHK(aux_begin(h));
+            const int rc = wrap_greens_slab(h, h->greens, h->greens_temp, h->current_slice - 1, 1);
+            aux_end(h);
+            CHK(rc);
+        }
+    }
     double *out = nullptr;
-    if (h->slab && !h->cb.on && h->s <= SLAB_MAX_STEPS) {  // the s products B_l' X = eV (eT2' X) in one launch
+    if (h->slab && !h->cb.on && h->s <= SLAB_MAX_STEPS) {  // the (remaining) products in one launch
         out = h->bufA;
         SlabArgs a = slab_base(h, X, h->nn, 0, out);
-        for (int t = 0; t < h->s; ++t) {
-            slab_step_const(h, a, h->eT2T);
-            a.st[t].post_conf = conf_slice(h, idx * h->s - t);
-            a.st[t].post_sign = +1;
-        }
-        a.col_d = dslot(h, idx); a.col_stride = h->n;  // stack.jl:305
+        chain_steps(h, a, dir, idx, t0, h->s);
+        a.col_d = dslot(h, src); a.col_stride = h->n;  // stack.jl:281 / :305
         CHK(run_slab(h, a));
     }
     else for (int t = 0; t < h->s; ++t) {
-        const int slice = idx * h->s - t;
+        const int slice = dir == 1 ? (idx - 1) * h->s + 1 + t : idx * h->s - t;
         out = (t & 1) ? h->bufB : h->bufA;
         if (h->cb.on) {
-            CHK(cb_mult(h, CB_LEFT_BDAG, slice, X, out, t == h->s - 1 ? dslot(h, idx) : nullptr));
+            CHK(cb_mult(h, dir == 1 ? CB_LEFT_B : CB_LEFT_BDAG, slice, X, out, t == h->s - 1 ? dslot(h, src) : nullptr));
             X = out;
             continue;
         }
-        GemmArgs g = gemm_base(h, C_(h, h->eT2), 1, U_(h, X), 0, out);  // (eT2*eV)' = eV*eT2'
-        g.rowscale = vs_conf(h, slice, +1);
-        g.row_first = 1;
-        if (t == h->s - 1) g.colscale = vs_arr(dslot(h, idx), h->n);  // stack.jl:305
+        GemmArgs g = gemm_base(h, C_(h, h->eT2), dir == 1 ? 0 : 1, U_(h, X), 0, out);  // (eT2*eV)' = eV*eT2'
+        if (dir == 1) g.kscale = vs_conf(h, slice, +1);
+        else { g.rowscale = vs_conf(h, slice, +1); g.row_first = 1; }
+        if (t == h->s - 1) g.colscale = vs_arr(dslot(h, src), h->n);
         CHK(run_gemm(h, g));
         X = out;
     }
+    // new factors into the spare, then slot dst <-> spare: the old slot dst stays readable.  The Q of the new slot is
+    // not needed before the second product of calculate_greens_AVX!: it is formed on the auxiliary stream
     const int sp = h->K + 1;
-    CHK(udt(h, out, uslot(h, sp), dslot(h, sp), h->tmp2, 1));
-    CHK(run_gemm(h, gemm_base(h, U_(h, h->tmp2), 0, U_(h, tslot(h, idx)), 0, tslot(h, sp))));
-    slot_swap_spare(h, idx - 1);
+    CHK(udt_factor(h, out, dslot(h, sp), h->tmp2, 1, h->qs[0]));
+    CHK(aux_begin(h));
+    const int rc = udt_formq(h, uslot(h, sp), h->qs[0], h->qs[0].winv, h->qs[0].ts);
+    aux_end(h);
+    CHK(rc);
+    CHK(run_gemm(h, gemm_base(h, U_(h, h->tmp2), 0, U_(h, tslot(h, src)), 0, tslot(h, sp))));
+    slot_swap_spare(h, dst);
     return 0;
 }
+static int add_slice_sequence_left(dqmc_handle *h, int idx, bool wrap_temp = false) { return add_slice_sequence(h, +1, idx, wrap_temp); }
+static int add_slice_sequence_right(dqmc_handle *h, int idx) { return add_slice_sequence(h, -1, idx, false); }
 
 // wrap_greens! (stack.jl:491-500), out of place, one launch: column slab c of the result is
 //   +1:  eT2 (eV (G (eV^-1 eTinv2[:, c])))          -1:  eV^-1 (eTinv2 (G eT2[:, c])) eV[c]
@@ -603,7 +713,7 @@ static int reset_slot(dqmc_handle *h, int slot)
 static int prop_check(dqmc_handle *h)
 {
     Timed t(h, DQMC_K_MISC);
-    HIPCHK(launch_prop_check(h->n, h->nb, h->W, h->greens_temp, h->greens, h->nn, h->stats, h->stream));
+    HIPCHK(launch_prop_check(h->n, h->nb, h->W, h->greens_temp, h->greens, h->nn, h->stats, h->pc_scratch, h->cur));
     return 0;
 }
 
@@ -620,6 +730,7 @@ static int init_stack(dqmc_handle *h)
 // stack.jl:242-255
 static int build_stack(dqmc_handle *h)
 {
+    h->chain.valid = false;
     CHK(reset_slot(h, 0));
     for (int i = 1; i <= h->K; ++i) CHK(add_slice_sequence_left(h, i));
     h->current_slice = h->M + 1;
@@ -641,17 +752,24 @@ static int propagate(dqmc_handle *h)
             } else if (1 < h->current_slice && h->current_slice <= M) {
                 const int idx = (h->current_slice - 1) / s;
                 const Udt R = slot_ref(h, idx);
-                CHK(add_slice_sequence_left(h, idx));
+                // stack.jl:534-536 wraps greens_temp unconditionally; its result is only observable through the
+                // check, so the wrap is skipped when the check is off.  (Slab form: out of place next to the
+                // slice sequence, on the auxiliary stream; it is awaited inside calculate_greens_src before
+                // anything overwrites mc.s.greens... which the first product there does: hence the join below.)
+                const bool wt = h->p.check_propagation_error != 0, wt_slab = wt && h->slab && !h->cb.on;
+                CHK(add_slice_sequence_left(h, idx, wt_slab));
                 const Udt L = slot_ref(h, idx);
-                if (h->p.check_propagation_error) {
-                    // stack.jl:534-536 wraps greens_temp unconditionally; its result is only
-                    // observable through the check, so the wrap is skipped when the check is off
-                    if (h->slab && !h->cb.on) {
-                        CHK(wrap_greens_slab(h, h->greens, h->greens_temp, h->current_slice - 1, 1));
-                    } else {
-                        CHK(copy_mat(h, h->greens_temp, h->greens));
-                        CHK(wrap_greens(h, &h->greens_temp, h->current_slice - 1, 1));
-                    }
+                if (wt && !wt_slab) {
+                    CHK(copy_mat(h, h->greens_temp, h->greens));
+                    CHK(wrap_greens(h, &h->greens_temp, h->current_slice - 1, 1));
+                }
+                if (wt_slab) {
+                    // the wrap reads mc.s.greens: the new Green's function goes to the other buffer of the pair
+                    // (greens_alt, free between two sweep_spatial calls) instead of waiting for it
+                    std::swap(h->greens, h->greens_alt);
+                    CHK(calculate_greens_src(h, h->greens, L, R));
+                    CHK(prop_check(h));
+                    return 0;
                 }
                 CHK(calculate_greens_src(h, h->greens, L, R));
                 if (h->p.check_propagation_error) CHK(prop_check(h));
@@ -678,7 +796,8 @@ static int propagate(dqmc_handle *h)
                 const Udt L = slot_ref(h, idx - 1);
                 CHK(add_slice_sequence_right(h, idx));
                 const Udt R = slot_ref(h, idx - 1);
-                if (h->p.check_propagation_error) CHK(copy_mat(h, h->greens_temp, h->greens));
+                // greens_temp = old Green's function (stack.jl:596-600): exchange the buffers instead of copying
+                if (h->p.check_propagation_error) std::swap(h->greens_temp, h->greens);
                 CHK(calculate_greens_src(h, h->greens, L, R));
                 if (h->p.check_propagation_error) CHK(prop_check(h));
                 CHK(wrap_greens(h, &h->greens, h->current_slice + 1, -1));
@@ -697,10 +816,17 @@ static int propagate(dqmc_handle *h)
 }
 
 // DQMC.jl:546-582
+static int sweep_spatial_launches(dqmc_handle *h);
 static int sweep_spatial(dqmc_handle *h)
 {
     const int l = h->current_slice;
     if (l < 1 || l > h->M) return fail(h, DQMC_ERR_STATE, "sweep_spatial: current_slice outside 1..slices");
+    CHK(sweep_spatial_launches(h));
+    return chain_advance(h, l);  // this slice's HS field is final for the current pass: next product of its interval
+}
+static int sweep_spatial_launches(dqmc_handle *h)
+{
+    const int l = h->current_slice;
     int8_t *cslice = h->conf + (long)(l - 1) * h->N;
     h->conf_version++;
     if (h->sweep_lu) {
@@ -714,19 +840,19 @@ static int sweep_spatial(dqmc_handle *h)
             const int nc = h->N / 64;
             timing_events(h, &a, &b);
             HIPCHK(launch_sweep_lu(h->n, h->nb, h->W, cur, h->nn, cslice, cstr, 0, 64, h->lu_img, h->sc, h->rng, h->stats,
-                                   h->p.check_sign_problem, h->qr_ws.errflag, h->stream, a, b));
+                                   h->p.check_sign_problem, h->qr_ws.errflag, h->cur, a, b));
             CHK(timing_push(h, a, b, DQMC_K_SWEEP));
             for (int c = 1; c < nc; ++c) {
                 timing_events(h, &a, &b);
                 HIPCHK(launch_sweep_fused(h->n, h->nb, h->W, cur, alt, h->nn, cslice, cstr, 64 * c, 64 * (c - 1),
                                           h->lu_img + (size_t)(c & 1) * istr, h->lu_img + (size_t)((c - 1) & 1) * istr, h->sc,
-                                          h->rng, h->stats, h->p.check_sign_problem, h->qr_ws.errflag, h->stream, a, b));
+                                          h->rng, h->stats, h->p.check_sign_problem, h->qr_ws.errflag, h->cur, a, b));
                 CHK(timing_push(h, a, b, DQMC_K_SWEEP));
                 std::swap(cur, alt);
             }
             timing_events(h, &a, &b);
             HIPCHK(launch_sweep_flush_lu(h->n, h->units, cur, alt, h->nn, 64 * (nc - 1), 64,
-                                         h->lu_img + (size_t)((nc - 1) & 1) * istr, h->stream, a, b));
+                                         h->lu_img + (size_t)((nc - 1) & 1) * istr, h->cur, a, b));
             CHK(timing_push(h, a, b, DQMC_K_FLUSH));
             std::swap(cur, alt);
             if (cur != h->greens) std::swap(h->greens, h->greens_alt);
@@ -736,10 +862,10 @@ static int sweep_spatial(dqmc_handle *h)
             const int ns = std::min(64, h->N - site0);
             timing_events(h, &a, &b);
             HIPCHK(launch_sweep_lu(h->n, h->nb, h->W, cur, h->nn, cslice, cstr, site0, ns, h->lu_img, h->sc,
-                                   h->rng, h->stats, h->p.check_sign_problem, h->qr_ws.errflag, h->stream, a, b));
+                                   h->rng, h->stats, h->p.check_sign_problem, h->qr_ws.errflag, h->cur, a, b));
             CHK(timing_push(h, a, b, DQMC_K_SWEEP));
             timing_events(h, &a, &b);
-            HIPCHK(launch_sweep_flush_lu(h->n, h->units, cur, alt, h->nn, site0, ns, h->lu_img, h->stream, a, b));
+            HIPCHK(launch_sweep_flush_lu(h->n, h->units, cur, alt, h->nn, site0, ns, h->lu_img, h->cur, a, b));
             CHK(timing_push(h, a, b, DQMC_K_FLUSH));
             std::swap(cur, alt);
         }
@@ -752,7 +878,7 @@ static int sweep_spatial(dqmc_handle *h)
             Timed t(h, DQMC_K_SWEEP);
             HIPCHK(launch_sweep_chunk(h->n, h->nb, h->W, h->p.model_kind, h->greens, h->nn, cslice, (long)h->N * h->M,
                                       site0, ns, h->sU, h->sVT, (long)h->n * h->kd, h->sc, h->rng, h->stats,
-                                      h->p.check_sign_problem, h->stream));
+                                      h->p.check_sign_problem, h->cur));
         }
         if (h->n % 64 == 0 && h->kd == 64) {  // dedicated flush kernel (whole K in LDS, C requested first)
             hipEvent_t a = nullptr, b = nullptr;
@@ -765,7 +891,7 @@ static int sweep_spatial(dqmc_handle *h)
                 };
                 a = get(); b = get();
             }
-            HIPCHK(launch_gemm_flush(h->n, h->units, h->sU, h->sVT, (long)h->n * h->kd, h->greens, h->nn, h->stream, a, b));
+            HIPCHK(launch_gemm_flush(h->n, h->units, h->sU, h->sVT, (long)h->n * h->kd, h->greens, h->nn, h->cur, a, b));
             if (h->timing) {
                 h->pending.push_back({a, b, DQMC_K_GEMM});
                 if (h->pending.size() >= 2048) CHK(timing_drain(h));
@@ -879,6 +1005,7 @@ int dqmc_create(const dqmc_params *p, dqmc_handle **out)
     } while (0)
     CHIP(hipSetDevice(p->device_id));
     CHIP(hipStreamCreate(&h->stream));
+    h->cur = h->stream;
     const size_t cn = (size_t)nb * h->nn, un = (size_t)h->units * h->nn, uv = (size_t)h->units * h->n;
     CCHK(dalloc(h, &h->eT, cn)); CCHK(dalloc(h, &h->eTinv, cn));
     CCHK(dalloc(h, &h->eT2, cn)); CCHK(dalloc(h, &h->eTinv2, cn));
@@ -912,9 +1039,33 @@ int dqmc_create(const dqmc_params *p, dqmc_handle **out)
                        &h->tmp2, &h->bufA, &h->bufB, &h->qrV, &h->qrW, &h->qrS};
     for (auto m : mats) CCHK(dalloc(h, m, un));
     CCHK(dalloc(h, &h->Dl, uv)); CCHK(dalloc(h, &h->Dr, uv)); CCHK(dalloc(h, &h->tau, uv));
-    CCHK(dalloc(h, &h->trsm_w, (size_t)h->units * ((h->n + 15) / 16) * 256));
+    const size_t wn = (size_t)h->units * ((h->n + 15) / 16) * 256;
+    CCHK(dalloc(h, &h->trsm_w, wn));
     if (h->n > 256) CCHK(dalloc(h, &h->trsm_s, un));
     CCHK(dalloc(h, &h->pivot, uv));
+    // DQMC_OVERLAP=1: independent kernels of a stabilisation step side by side on a second stream (the Q formation of a
+    // new stack slot and the up pass's wrap of the old Green's function next to the following factorisation).
+    // Measured at config 3 (gpurun_out/r03_overlap2.log): 70.0 against 70.3 ms per sweep - every
+    // kernel here holds most of a CU's LDS or registers, so two of them hardly ever share a CU, and each cross-stream
+    // dependency costs ~6 us on the main stream.  Off by default: one stream, one launch order.
+    if (getenv("DQMC_OVERLAP")) {
+        CHIP(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
+        CHIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        CHIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+        auto &q = h->qs[1];
+        CCHK(dalloc(h, &q.V, un)); CCHK(dalloc(h, &q.W, un)); CCHK(dalloc(h, &q.S, un));
+        CCHK(dalloc(h, &q.tau, uv)); CCHK(dalloc(h, &q.pivot, uv)); CCHK(dalloc(h, &q.winv, wn));
+        CCHK(dalloc(h, &h->aux_winv, wn));
+        if (h->n > 256) { CCHK(dalloc(h, &q.ts, un)); CCHK(dalloc(h, &h->aux_ts, un)); }
+        h->overlap_rdivp = getenv("DQMC_OVERLAP_RDIVP") != nullptr;
+        // look-ahead chain products (one per sweep_spatial, DQMC_CHAIN_AHEAD): measured slower - the slab kernels'
+        // 132 KB of LDS keep the product from sharing CUs with the wrap, so it delays the next elimination instead
+        if (h->slab && getenv("DQMC_CHAIN_AHEAD")) {
+            CCHK(dalloc(h, &h->chain.buf[0], un));
+            CCHK(dalloc(h, &h->chain.buf[1], un));
+        }
+        h->overlap = true;
+    }
     CCHK(alloc_qr_workspace(h));
     CCHK(dalloc(h, &h->sU, (size_t)h->units * h->n * h->kd));
     CCHK(dalloc(h, &h->sVT, (size_t)h->units * h->n * h->kd));
@@ -922,6 +1073,7 @@ int dqmc_create(const dqmc_params *p, dqmc_handle **out)
     CCHK(dalloc(h, &h->lu_img, 2 * (size_t)h->units * sweep_lu_image_doubles()));
     CCHK(dalloc(h, &h->rng, (size_t)h->W));
     CCHK(dalloc(h, &h->stats, (size_t)h->W));
+    CCHK(dalloc(h, &h->pc_scratch, 2 * (size_t)h->W));
     {
         std::vector<DevStats> st(h->W);
         for (auto &x : st) {
@@ -957,6 +1109,9 @@ int dqmc_destroy(dqmc_handle *h)
     for (void *q : h->allocs) (void)hipFree(q);
     for (double *u : h->uniforms)
         if (u) (void)hipFree(u);
+    if (h->aux) { (void)hipStreamSynchronize(h->aux); (void)hipStreamDestroy(h->aux); }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     ut_free(h);
     delete h;
@@ -975,9 +1130,11 @@ int dqmc_set_conf(dqmc_handle *h, int32_t w, const int8_t *conf)
     const size_t sz = (size_t)h->N * h->M;
     for (size_t i = 0; i < sz; ++i)
         if (conf[i] != 1 && conf[i] != -1) return fail(h, DQMC_ERR_INVALID, "conf entries must be +1 or -1");
+    if (h->aux) HIPCHK(hipStreamSynchronize(h->aux));
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(h->conf + (size_t)w * sz, conf, sz, hipMemcpyHostToDevice));
     h->conf_version++;
+    h->chain.valid = false;
     return DQMC_OK;
 }
 int dqmc_get_conf(dqmc_handle *h, int32_t w, int8_t *conf)
@@ -1035,6 +1192,10 @@ static int check_rng(dqmc_handle *h)
 int dqmc_synchronize(dqmc_handle *h)
 {
     ENTER(h);
+    if (h->aux) {
+        HIPCHK(hipStreamSynchronize(h->aux));
+        h->aux_pending = false;
+    }
     HIPCHK(hipStreamSynchronize(h->stream));
     CHK(timing_drain(h));
     CHK(check_qr_workspace(h));
@@ -1110,6 +1271,7 @@ int dqmc_get_greens_eff(dqmc_handle *h, int32_t w, double *out)
 int dqmc_set_greens_eff(dqmc_handle *h, int32_t w, const double *in)
 {
     ENTER(h); WALKER_OK(h, w);
+    if (h->aux) HIPCHK(hipStreamSynchronize(h->aux));
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(h->greens + (size_t)w * h->nb * h->nn, in, sizeof(double) * h->nb * h->nn, hipMemcpyHostToDevice));
     return DQMC_OK;
@@ -1232,6 +1394,7 @@ int dqmc_set_conf_bits(dqmc_handle *h, int32_t w, const uint64_t *chunks)
     ENTER(h); WALKER_OK(h, w);
     const size_t sz = (size_t)h->N * h->M, nch = (sz + 63) / 64;
     unsigned long long *d = nullptr;
+    if (h->aux) HIPCHK(hipStreamSynchronize(h->aux));
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMalloc((void **)&d, nch * sizeof(unsigned long long)));
     hipError_t e1 = hipMemcpy(d, chunks, nch * sizeof(unsigned long long), hipMemcpyHostToDevice);
@@ -1240,6 +1403,7 @@ int dqmc_set_conf_bits(dqmc_handle *h, int32_t w, const uint64_t *chunks)
     (void)hipFree(d);
     HIPCHK(e3);
     h->conf_version++;
+    h->chain.valid = false;
     return DQMC_OK;
 }
 
@@ -1694,6 +1858,7 @@ static int scratch_init(dqmc_handle *h, int device_id, int n, int batch)
     h->nn = (long)n * n;
     HIPCHK(hipSetDevice(device_id));
     HIPCHK(hipStreamCreate(&h->stream));
+    h->cur = h->stream;
     return 0;
 }
 static void scratch_free(dqmc_handle *h)

@@ -252,8 +252,9 @@ hipError_t launch_vec_map(int n, int nb, int units, double *dst, long stride, Ve
 hipError_t launch_scale_mat(int n, int nb, int units, double *O, const double *A, long stride, VecSrc row, VecSrc col,
                             int row_first, hipStream_t s);
 // per walker max|A-B| over its nb blocks; pushes log10 into stats.propagation_error if > 1e-7
+// scratch: 2 zero-initialised words per walker (partial maximum, arrival counter; left zeroed by every launch)
 hipError_t launch_prop_check(int n, int nb, int n_walkers, const double *A, const double *B,
-                             long stride_unit, DevStats *stats, hipStream_t s);
+                             long stride_unit, DevStats *stats, unsigned long long *scratch, hipStream_t s);
 // acc += sum over walkers of G, G.^2, 1-diag(G); layout documented in include/dqmc_hip.h
 hipError_t launch_accumulate(int n, int nb, int n_walkers, const double *G, long stride_unit,
                              double *acc, hipStream_t s);

@@ -442,29 +442,60 @@ hipError_t launch_fill(double *p, size_t n, double v, hipStream_t s)
 }
 
 // maximum(abs.(greens_temp - greens)) > 1e-7 -> push!(propagation_error, .) (stack.jl:538-549,602-611)
+// PC_SPLIT workgroups per walker: partial maxima meet in a per-walker word (non-negative doubles order like their bit
+// patterns), the last workgroup to arrive pushes the event and clears the scratch for the next launch
+constexpr int PC_SPLIT = 8;
 __global__ __launch_bounds__(1024) void prop_check_kernel(int n, int nb, const double *__restrict__ A,
                                                          const double *__restrict__ B, long stride_unit,
-                                                         DevStats *stats)
+                                                         DevStats *stats, unsigned long long *scratch)
 {
     __shared__ double red[16];
-    const int w = blockIdx.x;
+    const int w = blockIdx.x / PC_SPLIT, part = blockIdx.x % PC_SPLIT;
     const long tot = (long)nb * stride_unit;
-    const double *a = A + (long)w * tot, *b = B + (long)w * tot;
     double d = 0.0;
-    for (long i = threadIdx.x; i < tot; i += blockDim.x) d = fmax(d, fabs(a[i] - b[i]));
+    bool bad = false;  // a NaN anywhere makes the maximum NaN in the reference (maximum(abs.(...)))
+    if (tot & 1) {     // odd element count (odd n): the walkers' matrices are not all 16-byte aligned
+        const double *a = A + (long)w * tot, *b = B + (long)w * tot;
+        for (long i = (long)part * blockDim.x + threadIdx.x; i < tot; i += (long)PC_SPLIT * blockDim.x) {
+            const double e0 = fabs(a[i] - b[i]);
+            bad |= (e0 != e0);
+            d = fmax(d, e0);
+        }
+    } else {
+        const double2 *a = reinterpret_cast<const double2 *>(A + (long)w * tot), *b = reinterpret_cast<const double2 *>(B + (long)w * tot);
+        for (long i = (long)part * blockDim.x + threadIdx.x; i < tot / 2; i += (long)PC_SPLIT * blockDim.x) {
+            const double2 x = a[i], y = b[i];
+            const double e0 = fabs(x.x - y.x), e1 = fabs(x.y - y.y);
+            bad |= (e0 != e0) | (e1 != e1);
+            d = fmax(d, fmax(e0, e1));
+        }
+    }
+    if (bad) d = __longlong_as_double(0x7ff8000000000000ll);
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) d = fmax(d, __shfl_xor(d, off, 64));
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_xor(d, off, 64);
+        d = (d != d || o != o) ? __longlong_as_double(0x7ff8000000000000ll) : fmax(d, o);
+    }
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int i = 1; i < (int)(blockDim.x >> 6); ++i) d = fmax(d, red[i]);
-        if (d > 1e-7) magstats_push(stats[w].propagation_error, d);
+        for (int i = 1; i < (int)(blockDim.x >> 6); ++i) d = (d != d || red[i] != red[i]) ? __longlong_as_double(0x7ff8000000000000ll) : fmax(d, red[i]);
+        // NaN (0x7ff8...) sorts above every finite magnitude as an unsigned word: it survives the atomicMax
+        atomicMax(&scratch[2 * w], (unsigned long long)__double_as_longlong(d));
+        __threadfence();
+        if (atomicAdd(&scratch[2 * w + 1], 1ull) == PC_SPLIT - 1) {
+            __threadfence();
+            const double m = __longlong_as_double((long long)atomicExch(&scratch[2 * w], 0ull));
+            scratch[2 * w + 1] = 0ull;
+            if (m > 1e-7) magstats_push(stats[w].propagation_error, m);
+        }
     }
 }
 hipError_t launch_prop_check(int n, int nb, int n_walkers, const double *A, const double *B, long stride_unit,
-                             DevStats *stats, hipStream_t s)
+                             DevStats *stats, unsigned long long *scratch, hipStream_t s)
 {
-    hipLaunchKernelGGL(prop_check_kernel, dim3(n_walkers), dim3(1024), 0, s, n, nb, A, B, stride_unit, stats);
+    hipLaunchKernelGGL(prop_check_kernel, dim3(n_walkers * PC_SPLIT), dim3(1024), 0, s, n, nb, A, B, stride_unit, stats,
+                       scratch);
     return hipGetLastError();
 }
 

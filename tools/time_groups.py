@@ -10,8 +10,8 @@ for W in (32, 16, 8):
     mc = m.DQMC(m.HubbardModelAttractive(16, 2), beta=8.0, n_walkers=W)
     mc.prepare(); mc.sweep(1)
     t0 = time.perf_counter(); mc.sweep(NS); dt = (time.perf_counter() - t0) / NS
-    mc.timing_enable(True); mc.sweep(NS); ms, cnt = mc.timing(); mc.timing_enable(False)
-    print("alone W=%2d: %.1f ms/sweep | " % (W, dt * 1e3) + "  ".join("%s %.1f (%d)" % (f, ms[i] / NS, cnt[i] // NS) for i, f in enumerate(FAM)), flush=True)
+    mc.timing_enable(True); mc.sweep(NS); tm = mc.timing(); mc.timing_enable(False)
+    print("alone W=%2d: %.1f ms/sweep | " % (W, dt * 1e3) + "  ".join("%s %.1f (%d)" % (f, v[0] / NS, v[1] // NS) for f, v in tm.items()), flush=True)
     mc.close()
 TOT = 32
 for groups, off in ((1, 0), (2, 0), (2, 40), (2, 80), (4, 0), (4, 40)):
