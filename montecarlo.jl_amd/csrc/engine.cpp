@@ -217,6 +217,7 @@ static GemmArgs gemm_base(dqmc_handle *h, MatRef A, int tA, MatRef B, int tB, do
     g.alpha = 1.0;
     g.ident = 0.0;
     g.beta = 0;
+    g.tri = 0;
     return g;
 }
 static MatRef U_(dqmc_handle *h, const double *p) { return mat(p, h->nn, h->n); }        // per unit
@@ -397,6 +398,7 @@ static int udt_formq(dqmc_handle *h, double *Uout, QrSet &q, double *winv, doubl
 {
     const int n = h->n;
     GemmArgs g = gemm_base(h, U_(h, q.V), 1, U_(h, q.V), 0, q.S);
+    g.tri = (n % 64 == 0) ? 1 : 0;  // V is unit lower triangular: a third of the k range on average
     CHK(run_gemm(h, g));
     {
         Timed t(h, DQMC_K_TRSM);
@@ -405,6 +407,7 @@ static int udt_formq(dqmc_handle *h, double *Uout, QrSet &q, double *winv, doubl
     g = gemm_base(h, U_(h, q.W), 0, U_(h, q.V), 1, Uout);
     g.alpha = -1.0;
     g.ident = 1.0;
+    g.tri = (n % 64 == 0) ? 2 : 0;
     CHK(run_gemm(h, g));
     return 0;
 }

@@ -98,7 +98,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, int tiles_m, int 
     const int unit = (seq / T) * 8 + xcd;
     if (unit >= g.n_units) return;
     const int tile = seq % T;
-    const int m0 = (tile % tiles_m) * BM, n0 = (tile / tiles_m) * BN;
+    int m0 = (tile % tiles_m) * BM, n0 = (tile / tiles_m) * BN;
+    int kbeg = 0, kend = g.K;
+    if (g.tri == 1) {        // V'V: tiles below the diagonal are not needed, the sum starts at max(m0, n0) = n0
+        if (m0 > n0) return;
+        kbeg = n0;
+    } else if (g.tri == 2) { // A V': V[n, k] = 0 for k > n
+        kend = min(g.K, n0 + BN);
+    }
     const int blk = unit % g.nb;
 
     const double *__restrict__ A = g.A.p + (long)unit * g.A.stride_unit + (long)blk * g.A.stride_blk;
@@ -115,7 +122,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, int tiles_m, int 
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
 
-    const int nk = (g.K + BK - 1) / BK;
+    const int nk = (kend - kbeg + BK - 1) / BK;
     // Register ring of two k-tiles: the loads of tile kt+2 are issued before the MFMAs of tile kt, so a tile
     // has two iterations to arrive (with 32 units the grid gives each CU only two workgroups, and one
     // iteration of MFMA work is shorter than an L2 round trip).
@@ -131,7 +138,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, int tiles_m, int 
     const int kw = unit / g.nb, kblk = unit - kw * g.nb;
 
     auto load = [&](int kt, double (&qa)[4], double (&qb)[4], double (&qd)[NKS], int (&qc)[NKS]) {
-        const int k0 = kt * BK;
+        const int k0 = kbeg + kt * BK;
         tile_load<TA, FULL>(A, g.A.ld, m0, g.M, k0, g.K, tid, qa);
         tile_load<!TB, FULL>(B, g.B.ld, n0, g.N, k0, g.K, tid, qb);
         if (ksmode != 0) {

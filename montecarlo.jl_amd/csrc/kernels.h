@@ -63,6 +63,14 @@ struct GemmArgs {
     double alpha;   // scale of the product
     double ident;   // added on the diagonal
     int beta;       // 0: overwrite, 1: accumulate into C
+    // structure of the compact-WY operands (V = unit lower triangular Householder vectors with explicit zeros, M = N = K):
+    //   1: C = V' V, only the 64 x 64 tiles on and above the diagonal are computed, k >= max(m0, n0) (the rest of the
+    //      sum is zero; the triangle below the diagonal tiles is left untouched: nothing reads it)
+    //   2: C = A V', k < n0 + 64 (V[n, k] = 0 for k > n)
+    // (measured at 32 units, n = 256: no change of the launch time - 24.4 us either way: the launch lasts as long as
+    // its full-k tiles, and those run at the chip's sustained fp64 MFMA rate, 45.7 TF/s = 23.5 us per 2 n^3 x 32; the
+    // skipped work only saves power.  A k-tile of 32 instead of 16 did not change it either.)
+    int tri;
 };
 // start/stop (optional): events that take the dispatch's own begin/end timestamps (hipExtLaunchKernelGGL),
 // i.e. the kernel-only duration a profiler's kernel trace reports

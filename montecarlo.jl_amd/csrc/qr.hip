@@ -1464,14 +1464,16 @@ __global__ __launch_bounds__(256) void udt_diag_kernel(int n, int n_units, const
 }
 
 // D, V and T from the factored matrix (UDT.jl:268-306).  One workgroup per unit.
-constexpr int UF_SPLIT = 8;  // workgroups per matrix (column slabs): 32 matrices alone would leave 7/8 of the chip idle
+// workgroups per matrix (interleaved columns): a pure copy / scale pass over 3 n^2 doubles per matrix, bandwidth-bound;
+// 32 matrices x 8 workgroups left the CUs at one workgroup each (20.6 us per batch at n = 256, 2.4 TB/s)
+static inline int uf_split(int n) { return n >= 128 ? 32 : 8; }
 __global__ __launch_bounds__(256) void udt_finish_kernel(int n, double *Aall, long strideA,
                                                         const double *Fall, long strideF,
                                                         const int *__restrict__ pivall,
                                                         double *__restrict__ Dall, long strideD,
                                                         double *__restrict__ Vall, long strideV,
                                                         double *__restrict__ Tall, long strideT, int apply_pivot,
-                                                        int d_ready)
+                                                        int d_ready, int UF_SPLIT)
 {
     extern __shared__ __attribute__((aligned(16))) double dinv[];  // 1/D
     const int unit = blockIdx.x / UF_SPLIT, slab = blockIdx.x % UF_SPLIT;
@@ -1518,8 +1520,9 @@ hipError_t launch_udt_finish(int n, int n_units, double *A, long strideA, const 
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(udt_finish_kernel, dim3(n_units * UF_SPLIT), dim3(256), n * sizeof(double), s, n, A, strideA,
-                       F, strideF, pivot, D, strideD, V, strideV, Tout, strideT, apply_pivot, d_ready);
+    const int split = uf_split(n);
+    hipLaunchKernelGGL(udt_finish_kernel, dim3(n_units * split), dim3(256), n * sizeof(double), s, n, A, strideA,
+                       F, strideF, pivot, D, strideD, V, strideV, Tout, strideT, apply_pivot, d_ready, split);
     return hipGetLastError();
 }
 
