@@ -654,6 +654,7 @@ __device__ __forceinline__ double qc_apply(double (&x)[32], const double *vq, do
         const double y0 = x[k] - vv[k >> 1].x * wv, y1 = x[k + 1] - vv[k >> 1].y * wv;
         x[k] = y0;
         x[k + 1] = y1;
+#ifndef QR_NONORM_EXPERIMENT
         if (k < KB0 + 4) {  // only the region's own 32 rows can be <= j
             n0 += (rg + 8 * k > j ? 1.0 : 0.0) * (y0 * y0);
             n1 += (rg + 8 * (k + 1) > j ? 1.0 : 0.0) * (y1 * y1);
@@ -661,8 +662,13 @@ __device__ __forceinline__ double qc_apply(double (&x)[32], const double *vq, do
             n0 += y0 * y0;
             n1 += y1 * y1;
         }
+#endif
     }
+#ifdef QR_NONORM_EXPERIMENT  // timing experiment only (wrong pivots): what a step costs without the fresh norms
+    return wv * 1e-300 + 1.0;
+#else
     return sum8(n0 + n1);
+#endif
 }
 
 __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double *__restrict__ Aall, long strideA,
@@ -1127,6 +1133,7 @@ __device__ __forceinline__ void qb_step(int t, double (&x)[QbGeo<J0, NW>::CPT][Q
             const double y0 = __builtin_fma(-u[k], wv[c], x[c][k]), y1 = __builtin_fma(-u[k + 1], wv[c], x[c][k + 1]);
             x[c][k] = y0;
             x[c][k + 1] = y1;
+#ifndef QR_NONORM_EXPERIMENT
             if (k < KB0 + 4) {
                 n0 += (J0 + rg + 8 * k > j ? 1.0 : 0.0) * (y0 * y0);
                 n1 += (J0 + rg + 8 * (k + 1) > j ? 1.0 : 0.0) * (y1 * y1);
@@ -1134,11 +1141,18 @@ __device__ __forceinline__ void qb_step(int t, double (&x)[QbGeo<J0, NW>::CPT][Q
                 n0 = __builtin_fma(y0, y0, n0);
                 n1 = __builtin_fma(y1, y1, n1);
             }
+#endif
         }
+#ifdef QR_NONORM_EXPERIMENT
+        nrm[c] = nrm[c] * 0.999 + wv[c] * 1e-300;
+#else
         nrm[c] = n0 + n1;
+#endif
     }
+#ifndef QR_NONORM_EXPERIMENT
 #pragma unroll
     for (int c = 0; c < CPT; ++c) nrm[c] = sum8(nrm[c]);
+#endif
     QB_STAMP(7)
 }
 
@@ -1225,6 +1239,7 @@ __device__ __forceinline__ void qf_step(int t, double (&x)[64], double &nrm, int
             const double y0 = __builtin_fma(-uu.x, wv, x[R0 + i]), y1 = __builtin_fma(-uu.y, wv, x[R0 + i + 1]);
             x[R0 + i] = y0;
             x[R0 + i + 1] = y1;
+#ifndef QR_NONORM_EXPERIMENT
             if (i < 8) {
                 n0 += (R0 + i > t ? 1.0 : 0.0) * (y0 * y0);
                 n1 += (R0 + i + 1 > t ? 1.0 : 0.0) * (y1 * y1);
@@ -1232,8 +1247,13 @@ __device__ __forceinline__ void qf_step(int t, double (&x)[64], double &nrm, int
                 n0 = __builtin_fma(y0, y0, n0);
                 n1 = __builtin_fma(y1, y1, n1);
             }
+#endif
         }
+#ifdef QR_NONORM_EXPERIMENT
+        nrm = nrm * 0.999 + wv * 1e-300;
+#else
         nrm = n0 + n1;
+#endif
     }
 }
 
