@@ -1,12 +1,20 @@
 """Comparison of an independent sampler with the statistical goldens the reference holds for its own seeded runs
 (test/integration_tests.jl:29-185).  The goldens are means of ONE run of 100 measurements under Julia's
 MersenneTwister stream, which cannot be reproduced here; next to every mean the reference also stores the
-std_error of that run.  Rules (tolerances are the reference's own, nothing is widened):
+std_error of that run.  Rules (tolerances are the reference's own; the one widened limit is explained in rule 1):
 
   1. every element: |ours - golden| <= Z * sqrt(se_golden^2 + se_ours^2)   (Z = 4.5; exact zeros must be exact).
-     For the 400 pairing-correlation elements Z = 6.5: their published std_errors go down to 1e-5 (0.4 % of the
-     value, from 100 measurements after 10 thermalisation sweeps) and a 6000-sample device run resolves offsets of
-     1e-4 there - 300 times below the reference's own atol of 0.04, which rule 2 holds for all 400 elements.
+     For the 400 pairing-correlation elements Z = 6.5 - the one place where a limit is wider than 4.5 sigma.  Their
+     published std_errors go down to 1e-5 (0.4 % of the value, from 100 measurements after 10 thermalisation sweeps)
+     and a 6000-sample run resolves offsets of 1e-4 there - 300 times below the reference's own atol of 0.04, which
+     rule 2 holds for all 400 elements.  The offsets belong to the GOLDEN, not to our pairing kernel: an independent
+     CPU run of the oracle with the python formulas of oracle/ref_test_oracle.py (6 chains x 3000 measurements,
+     tools/pc_offsets.py, profiles/r03_pc_offsets.txt) shows the same elements at the same distance (max |z| 6.2, nine
+     elements above 4.5 - e.g. (dir 14, 4, 3): golden -0.005327 +- 0.000022, oracle -0.005193 +- 0.000005, device
+     -0.005194) while oracle and device agree with each other (mean z^2 1.4 with the oracle's error alone).  The
+     outliers sit on symmetry-related elements with nearly equal golden values, i.e. they are one fluctuation of the
+     reference's single 100-measurement run (its 10 thermalisation sweeps from a random field included), counted
+     several times, with a std_error estimated from those same 100 correlated samples.
   2. where the reference test carries an atol A: every element agrees within A itself (all_at_atol: CDC, SDC, PC,
      magnetisations), or - for the Green's function, whose diagonal has a published std_error of 0.019 against
      A = 0.04, and for the recorded HS field (std_error 0.1) - every element whose own published standard error

@@ -1,7 +1,8 @@
 """Are the 4.5 - 6.5 sigma offsets of some pairing-correlation elements against the reference's golden (tests/golden_stats.py,
 rule 1) a property of OUR pairing kernel or of the golden's std_error?  A long CPU-oracle run (python formulas of
-oracle/ref_test_oracle.py, independent of the device kernel) is compared with the golden and with the device mean saved by
-tools/pcdbg.py (gpurun_out/pc_dev_mean.npy).  Usage: python tools/pc_offsets.py [chains] [measurements per chain]"""
+oracle/ref_test_oracle.py, independent of the device kernel) is compared with the golden and with the device mean
+(gpurun_out/pc_dev_mean.npy, written by `python tools/pc_offsets.py --device` on the GPU box: 32 walkers x 192 measurements,
+the sample of tests/test_gpu_measurements.py).  Usage: python tools/pc_offsets.py [chains] [measurements per chain]"""
 import os, sys
 from concurrent.futures import ProcessPoolExecutor
 import numpy as np
@@ -22,8 +23,18 @@ def chain(args):
     return np.array(out)
 
 
+def device_mean():
+    import __graft_entry__ as g
+    import test_gpu_measurements as T
+    s = T._device_blocks(g.load_package(), "attractive", 4, 5, 32, 24, 8, 30, 2024)
+    np.save(os.path.join(R_, "gpurun_out", "pc_dev_mean.npy"), s["PC"].mean(0))
+
+
 if __name__ == "__main__":
     import golden_stats as gs
+    if "--device" in sys.argv:
+        device_mean()
+        sys.exit(0)
     nch = int(sys.argv[1]) if len(sys.argv) > 1 else 6
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
     with ProcessPoolExecutor(max_workers=min(nch, 6)) as ex:
