@@ -356,9 +356,21 @@ __device__ __noinline__ void lu4_wave(int n, const double *__restrict__ Gall, lo
     }
     if (PRO) {
         LU4_STAMP(400 + 8 * J + 0);
-        // LDS scratch aliased onto the (not yet used) step ring: R0 block [64 t'][66] and the T' tiles of waves 0..2
-        double *Rl = reinterpret_cast<double *>(&sm.aST[0][0][0]);
-        double *ttx = Rl + 64 * 66;
+        // EARLY (one block per walker, images staged in LDS): wave 0 - the first pivot - only adds what its own diagonal
+        // tile needs (two tile products) and starts the site loop, while waves 1..3 finish the block update behind
+        // its first sixteen decisions; the products of block row 0 that wave 0 used to make for them (S tiles (0, Jc))
+        // are made by their owners from wave 0's T' tiles, which it leaves in LDS.  The scratch must then stay clear of
+        // the ring slots the first pivots write: the R0 block [64 t'][66] sits on slots 31..63 (exactly 33 slots;
+        // a pivot of block >= 1 waits for the three "products done" flags before it writes its first slot), deltas,
+        // wave 0's T' and the flags behind the staged images.  Otherwise (NB == 2: no LDS left) everything is aliased
+        // onto the not yet used ring and all four waves meet at two barriers before the first decision.
+        constexpr bool EARLY = (NB == 1) && (sizeof(Lu4Smem<NB>) + LU_STRIDE * sizeof(double) <= 150 * 1024);
+        double *xtra = lu4_lds + (sizeof(Lu4Smem<NB>) + 15) / 16 * 2 + LU_STRIDE;  // [deltas 1536][T' of wave 0 1024][flags]
+        double *Rl = EARLY ? reinterpret_cast<double *>(&sm.aST[0][31][0]) : reinterpret_cast<double *>(&sm.aST[0][0][0]);
+        double *ttx = EARLY ? xtra : Rl + 64 * 66;
+        double *tt0 = xtra + 1536;
+        int *pflag = reinterpret_cast<int *>(xtra + 1536 + 1024);  // [0] T' of wave 0 published, [J] deltas of wave J
+                                                                   // written, [4 + J] wave J is done with the scratch
         const int tid = threadIdx.x;
 #pragma unroll 1
         for (int b = 0; b < NB; ++b) {
@@ -463,6 +475,65 @@ __device__ __noinline__ void lu4_wave(int n, const double *__restrict__ Gall, lo
 #undef PRO_P
 #undef PRO_Q
             LU4_STAMP(400 + 8 * J + 3);
+            if (EARLY) {
+                double *dlt = ttx;  // [pair (J, Jc)][4 regs][64 lanes]
+                if (J == 0) {
+#pragma unroll
+                    for (int K = 0; K < 4; ++K)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) tt0[(K * 4 + q) * 64 + lane] = tt[K][q];
+                    LU4_ORDER();
+                    __hip_atomic_store(&pflag[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+                    for (int K = 0; K < 4; ++K)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int sk = 16 * K + 4 * q + g;
+                            ST[b][0] = MFMA(Rl[ci * 66 + sk], tt[K][q], ST[b][0]);
+                            S[b][0] = MFMA(tt[K][q], Rl[ci * 66 + sk], S[b][0]);
+                        }
+                } else {
+                    // own T' rows: S' tiles (I, J), I <= J; S tile (J, J); S tiles (J, Jc), Jc > J, as deltas for wave Jc
+#pragma unroll
+                    for (int K = 0; K < 4; ++K)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int sk = 16 * K + 4 * q + g;
+#pragma unroll
+                            for (int I = 0; I <= J; ++I) ST[b][I] = MFMA(Rl[(16 * I + ci) * 66 + sk], tt[K][q], ST[b][I]);
+                            S[b][J] = MFMA(tt[K][q], Rl[(16 * J + ci) * 66 + sk], S[b][J]);
+                        }
+#pragma unroll
+                    for (int Jc = J + 1; Jc < 4; ++Jc) {
+                        d4 dl = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int K = 0; K < 4; ++K)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) dl = MFMA(tt[K][q], Rl[(16 * Jc + ci) * 66 + 16 * K + 4 * q + g], dl);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) dlt[(lu_pair(J, Jc) * 4 + r) * 64 + lane] = dl[r];
+                    }
+                    LU4_ORDER();
+                    __hip_atomic_store(&pflag[J], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    // S tile (0, J) of block row 0 from wave 0's T' tiles
+                    if (lu4_wait(&pflag[0], &sm.abort) > 0) {
+#pragma unroll
+                        for (int K = 0; K < 4; ++K)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                S[b][0] = MFMA(tt0[(K * 4 + q) * 64 + lane], Rl[(16 * J + ci) * 66 + 16 * K + 4 * q + g], S[b][0]);
+                    }
+#pragma unroll
+                    for (int I = 1; I < J; ++I)
+                        if (lu4_wait(&pflag[I], &sm.abort) > 0) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) S[b][I][r] += dlt[(lu_pair(I, J) * 4 + r) * 64 + lane];
+                        }
+                    LU4_ORDER();
+                    __hip_atomic_store(&pflag[4 + J], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                continue;
+            }
             // Block update, five tile products of 16 MFMAs on every wave: wave J computes what needs ITS OWN T' rows -
             // the S' tiles (I, J), I <= J, of its block column, and the S tiles (J, Jc), Jc >= J, of block ROW J.  The
             // latter belong to wave Jc for Jc > J: they go there as deltas through LDS.  (Ownership by block column
@@ -537,8 +608,23 @@ __device__ __noinline__ void lu4_wave(int n, const double *__restrict__ Gall, lo
         double negv = 0.0;
         // The diagonal entry the next decision needs is carried as a scalar: S[s+1][s+1] + x S[s+1][s] S[s][s+1]
         // from registers that the MFMAs of site s have not touched yet, so a decision never waits for an MFMA.
+        // helper side: flag and payload of the NEXT site are requested before the MFMAs of the current one, so that a
+        // helper that is behind (after the prologue, after a panel end) works through the ring at MFMA pace instead of
+        // one LDS round trip per site; a request that came too early (flag not yet set) is repeated by the spin loop
+        int pf_v = 0;
+        double2 pf_pay[NB];
+        double pf_xh[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) { pf_pay[b] = make_double2(0.0, 0.0); pf_xh[b] = 0.0; }
         double dcur[NB];
         if (PIV) {
+            if (PRO && NB == 1 && I0 >= 1 && sizeof(Lu4Smem<NB>) + LU_STRIDE * sizeof(double) <= 150 * 1024) {
+                // EARLY prologue: the R0 block lies on ring slots 31..63 until waves 1..3 are done with it
+                int *pflag = reinterpret_cast<int *>(lu4_lds + (sizeof(Lu4Smem<NB>) + 15) / 16 * 2 + LU_STRIDE + 1536 + 1024);
+                (void)lu4_wait(&pflag[5], &sm.abort);
+                (void)lu4_wait(&pflag[6], &sm.abort);
+                (void)lu4_wait(&pflag[7], &sm.abort);
+            }
 #pragma unroll
             for (int b = 0; b < NB; ++b) dcur[b] = readlane_d(S[b][J][0], 0);
         }
@@ -615,10 +701,12 @@ __device__ __noinline__ void lu4_wave(int n, const double *__restrict__ Gall, lo
                 } else {
                     // flag and payload are requested together (in this order); the payload is only valid if the
                     // flag was already set
-                    int v = 0;
+                    int v = c > 0 ? __builtin_amdgcn_readfirstlane(pf_v) : 0;
                     double2 pay[NB];
                     double xh[NB];
-                    for (int it = 0; it < LU4_SPIN; ++it) {
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) { pay[b] = pf_pay[b]; xh[b] = pf_xh[b]; }
+                    for (int it = 0; v == 0 && it < LU4_SPIN; ++it) {
                         const int vr = __hip_atomic_load(&sm.step[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         LU4_ORDER();
 #pragma unroll
@@ -640,6 +728,15 @@ __device__ __noinline__ void lu4_wave(int n, const double *__restrict__ Gall, lo
                         v = -1;
                     }
                     if (v > 0) lastflag = v;
+                    if (c < 15 && (FULL || s + 1 < nsites)) {  // next site of this block: request it now
+                        pf_v = __hip_atomic_load(&sm.step[s + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        LU4_ORDER();
+#pragma unroll
+                        for (int b = 0; b < NB; ++b) {
+                            pf_pay[b] = sm.aST[b][s + 1][lane];
+                            pf_xh[b] = sm.xs[b][s + 1];
+                        }
+                    }
                     LU4_STAMP(64 * (1 + J) + s);
                     if (v > 0 && (v & 3) == 2) {
                         panel_acc |= 1u << ks;
@@ -750,6 +847,8 @@ __device__ __forceinline__ void lu4_block(int w, int n, const double *__restrict
 #endif
     if (tid < 4) { sm.acc16[tid] = 0u; sm.neg16[tid] = 0u; sm.ndraw[tid] = 0; sm.exh[tid] = 0; }
     if (tid == 0) sm.abort = 0;
+    if (PRO && NB == 1 && tid < 8)  // flags of the EARLY prologue (lu4_wave)
+        reinterpret_cast<int *>(lu4_lds + (sizeof(Lu4Smem<NB>) + 15) / 16 * 2 + LU_STRIDE + 1536 + 1024)[tid] = 0;
     __syncthreads();
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     if (wv == 0) lu4_wave<NB, FULL, PRO, 0>(n, Gall, strideG, w, site0, nsites, img_all, sc, cbits, uvec, check_sign, site0p, imgp_all);
@@ -1121,7 +1220,8 @@ hipError_t launch_sweep_fused(int n, int nb, int n_walkers, const double *Gin, d
     const size_t lds_flush = ((size_t)LU_STRIDE + 16 * nt * FL_LDR) * sizeof(double);
     const size_t lds_lu = nb == 1 ? sizeof(Lu4Smem<1>) : sizeof(Lu4Smem<2>);
     // NB == 1: the prologue stages the previous chunk's images behind the shared structure (lu4_wave, STAGE)
-    const size_t lds_pro = nb == 1 ? (sizeof(Lu4Smem<1>) + 15) / 16 * 16 + LU_STRIDE * sizeof(double) : lds_lu;
+    // + deltas (1536 doubles), wave 0's T' tiles (1024), flags (EARLY prologue)
+    const size_t lds_pro = nb == 1 ? (sizeof(Lu4Smem<1>) + 15) / 16 * 16 + (LU_STRIDE + 1536 + 1024 + 8) * sizeof(double) : lds_lu;
     const size_t lds_e = lds_pro > lds_lu ? lds_pro : lds_lu;
     const size_t lds = lds_flush > lds_e ? lds_flush : lds_e;
     int dev = 0;

@@ -199,7 +199,7 @@ class DQMC:
         self._h = C.c_void_p()
         check(lib().dqmc_create(C.byref(prm), C.byref(self._h)))
         # checkerboard=True picks the faster execution of the same decomposition: measured on MI355X (config 3 shape,
-        # tools/timeit.py checkerboard) the sparse-factor kernel takes 32.5 us per product against 31.2 us for the dense
+        # tools/time_parts.py checkerboard) the sparse-factor kernel takes 32.5 us per product against 31.2 us for the dense
         # MFMA GEMM with the multiplied-out constants at n = 256, so dense up to n = 256 and sparse (O(n^2) work per
         # product) above; checkerboard="sparse" / "dense" force one
         sparse = checkerboard == "sparse" or (checkerboard is True and self.N > 256)

@@ -1,9 +1,9 @@
 """A/B timing of parts of the engine on the GPU box (one tool instead of a script per question).
-  python tools/timeit.py families [walkers] [attractive|repulsive]   per-family device ms of one sweep (config 3 / 4 shape)
-  python tools/timeit.py wrap [walkers]                              us per wrap_greens launch, TFLOP/s
-  python tools/timeit.py sweep_spatial                               us per launch of the site-sweep phase
-  python tools/timeit.py checkerboard                                dense constants against the sparse bond-group kernel
-  python tools/timeit.py soak [sweeps]                               two identical long runs: bit-identical HS fields?
+  python tools/time_parts.py families [walkers] [attractive|repulsive]   per-family device ms of one sweep (config 3 / 4 shape)
+  python tools/time_parts.py wrap [walkers]                              us per wrap_greens launch, TFLOP/s
+  python tools/time_parts.py sweep_spatial                               us per launch of the site-sweep phase
+  python tools/time_parts.py checkerboard                                dense constants against the sparse bond-group kernel
+  python tools/time_parts.py soak [sweeps]                               two identical long runs: bit-identical HS fields?
 Kernel-selection switches are environment variables read per handle."""
 import hashlib, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
