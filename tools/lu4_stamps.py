@@ -43,4 +43,5 @@ for rep in range(3):
         h = t[64 * (1 + J):64 * (2 + J)]
         lag = [int(h[s] - piv[s]) for s in range(0, 16 * J, 3)]
         print(" helper %d lag behind the pivot's decision stamp:" % J, lag)
+        print(" helper %d own site-to-site deltas, block 0:" % J, np.diff(h[:16]).tolist())
 mc.close()
