@@ -686,8 +686,12 @@ __device__ __noinline__ void lu4_wave(int n, const double *__restrict__ Gall, lo
                             const double mS = lm2 ? S[b][J][r0] : 0.0, mT = lm2 ? ST[b][J][r0] : 0.0;
                             const double aS = x * mT, aT = x * mS;
                             if (more) {
-                                const double t = readlane_d(aS * mS, 16 * ks + c1);  // x S[s+1][s] S[s][s+1]
-                                dcur[b] = readlane_d(S[b][J][c1 >> 2], l1) + t;
+                                // next diagonal entry S[s+1][s+1] + x S[s+1][s] S[s][s+1]: the product of the two
+                                // off-diagonal entries and the old diagonal entry do not depend on this site's
+                                // decision (only on the tile as site s - 1 left it), so they are taken out of the tile
+                                // BEFORE x is known and the chain from decision to decision ends with one FMA
+                                const double qs = readlane_d(mT * mS, 16 * ks + c1);
+                                dcur[b] = __builtin_fma(x, qs, readlane_d(S[b][J][c1 >> 2], l1));
                             }
                             S[b][J] = MFMA(aS, mS, S[b][J]);
                             sm.aST[b][s][lane] = make_double2(aS, aT);
