@@ -180,6 +180,270 @@ __global__ __launch_bounds__(QR_THREADS) void qr_pivot_kernel(int n, double *__r
 }
 
 // ---------------------------------------------------------------------------
+// Panel form for n > 256 (config 5: n = 576), one workgroup per matrix.  The streaming kernel above moves the whole
+// trailing matrix through the workgroup twice per step (read + write): at n = 576 with 256 matrices that is 390 GB per
+// batch, i.e. the kernel sits on the HBM roofline of the unblocked algorithm (49.5 ms per batch, 5.3 TB/s).  This one
+// keeps the reference's pivot rule but reorganises the arithmetic the way LAPACK's dlaqps does, so that a step READS the
+// trailing matrix once and writes nothing but one row:
+//   * panels of QP_NB columns; inside a panel the reflectors are NOT applied to the trailing matrix.  Step j = j0 + k:
+//     pivot = first maximum of the trailing column norms; the pivot column alone is brought up to date
+//     (a -= V[:, 0:k] F[j, 0:k]'), its norm is taken from scratch (as the reference takes it, UDT.jl:151-168) and the
+//     reflector built (UDT.jl:133-148); F[:, k] = tau A' v over the not yet updated trailing matrix - the one pass
+//     over memory -, corrected by the earlier reflectors of the panel; row j of the trailing matrix is updated
+//     (it is row j of R);
+//   * the norms of the other columns are DOWN-DATED with that row (|a_c|^2 -= r_jc^2) instead of recomputed - the one
+//     departure from the reference's arithmetic (it recomputes every norm from the updated matrix at every step).  A
+//     column whose norm has lost four digits since it was last computed exactly (|a_c|^2 <= 1e-4 of the reference value;
+//     LAPACK tolerates sqrt(eps)) is recomputed on the spot from the virtually updated column, so the norms that decide
+//     a pivot agree with the reference's to ~1e-9 relative and the pivot can differ only on such near-ties;
+//   * at the end of a panel the trailing matrix gets the rank-QP_NB update A -= V F' (one read + one write).
+// Traffic: (1 + 2 / QP_NB) passes per step instead of 2.  Arithmetic is negligible (a CU needs ~2 flops per cycle to keep up).
+// Output format as qr_pivot_kernel: R on / above the diagonal, Householder vectors below (unit diagonal implied).
+constexpr int QP_NB = 16;
+constexpr int QP_UC = 8;   // columns a wave keeps in flight in the pass over the trailing matrix: 72 requests per lane - the
+                           // loop does not overlap its iterations, so a group's requests are all the memory parallelism there is
+                           // (2 columns: 48 ms per batch at n = 576, latency-bound at 3 TB/s)
+constexpr int QP_UC2 = 4;  // columns per group in the rank-QP_NB update
+constexpr int QP_THREADS = 512, QP_WAVES = QP_THREADS / 64;  // 2 waves per SIMD: 256 VGPRs per lane (at 1024 threads the
+                                                             // 128-register budget spilled and the kernel ran 2.4 x slower)
+constexpr int QP_RPT = 2;  // rows per thread in the one-element-per-row phases (n <= 1024)
+template <int QMAX>
+__global__ __launch_bounds__(QP_THREADS) void qr_panel_kernel(int n, double *__restrict__ Aall, long strideA,
+                                                             double *__restrict__ tauall, int *__restrict__ pivall)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double *F = sm;                  // [QP_NB][n]: F[kk * n + c]
+    double *vn1 = F + QP_NB * n;     // squared partial norms (down-dated)
+    double *vn2 = vn1 + n;           // their values when last computed exactly
+    double *v = vn2 + n;             // current reflector: v[j] = 1, v[r < j] = 0
+    double *rowj = v + n;            // row j of the trailing matrix as the pass over it found it
+    double *aux = rowj + n;          // [2 QP_NB]: aux of the F update, row j of the panel's reflectors
+    double *red = aux + 2 * QP_NB;   // [QP_WAVES + 2]
+    int *todo = reinterpret_cast<int *>(red + QP_WAVES + 2);  // columns whose norm must be recomputed, [0] = count
+    __shared__ int s_jm;
+
+    const int unit = blockIdx.x;
+    double *__restrict__ A = Aall + (long)unit * strideA;
+    double *__restrict__ tau = tauall + (long)unit * n;
+    int *__restrict__ piv = pivall + (long)unit * n;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    for (int i = tid; i < n; i += QP_THREADS) piv[i] = i;
+    for (int c = wave; c < n; c += QP_WAVES) {
+        double s = 0.0;
+        for (int r = lane; r < n; r += 64) {
+            const double a = A[r + (long)n * c];
+            s += a * a;
+        }
+        s = wave_sum(s);
+        if (lane == 0) { vn1[c] = s; vn2[c] = s; }
+    }
+    if (tid == 0) todo[0] = 0;
+    __syncthreads();
+
+    for (int j0 = 0; j0 < n; j0 += QP_NB) {
+        const int kb = min(QP_NB, n - j0);
+        for (int i = tid; i < kb * n; i += QP_THREADS) F[i] = 0.0;
+        __syncthreads();
+        for (int k = 0; k < kb; ++k) {
+            const int j = j0 + k;
+            // ---- pivot: first maximum of the trailing column norms (UDT.jl:151-168)
+            if (wave == 0) {
+                double best = -1.0;
+                int bi = 0x7fffffff;
+                for (int c = j + lane; c < n; c += 64) {
+                    const double val = vn1[c];
+                    if (val > best) { best = val; bi = c; }
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const double ov = __shfl_xor(best, off, 64);
+                    const int oi = __shfl_xor(bi, off, 64);
+                    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+                }
+                if (lane == 0) s_jm = (bi < n) ? bi : j;
+            }
+            __syncthreads();
+            const int jm = s_jm;
+            // ---- swap columns j <-> jm (UDT.jl:219-231) together with their rows of F and their norms
+            if (jm != j) {
+                for (int rr = tid; rr < n; rr += QP_THREADS) {
+                    const double a = A[rr + (long)n * jm], b = A[rr + (long)n * j];
+                    A[rr + (long)n * j] = a;
+                    A[rr + (long)n * jm] = b;
+                }
+                if (tid < kb) {
+                    const double fa = F[tid * n + jm], fb = F[tid * n + j];
+                    F[tid * n + j] = fa;
+                    F[tid * n + jm] = fb;
+                }
+                if (tid == 0) {
+                    vn1[jm] = vn1[j]; vn2[jm] = vn2[j];
+                    const int t = piv[j]; piv[j] = piv[jm]; piv[jm] = t;
+                }
+            }
+            __syncthreads();
+            // ---- the pivot column, rows >= j, brought up to date with the reflectors of this panel.  (All loops over
+            // the panel run over the compile-time QP_NB with clamped addresses and zero coefficients: a run-time trip
+            // count, or a predicate on a load, turns sixteen independent requests into sixteen round trips.)
+            double a[QP_RPT];
+            double sq = 0.0;
+#pragma unroll
+            for (int e = 0; e < QP_RPT; ++e) {
+                const int r = tid + QP_THREADS * e, rc = min(r, n - 1);
+                a[e] = A[rc + (long)n * j];
+                double vp[QP_NB];
+#pragma unroll
+                for (int kk = 0; kk < QP_NB; ++kk) vp[kk] = A[rc + (long)n * (j0 + min(kk, kb - 1))];
+#pragma unroll
+                for (int kk = 0; kk < QP_NB; ++kk) a[e] -= ((kk < k && r >= j) ? F[kk * n + j] : 0.0) * vp[kk];
+                sq += (r < n && r >= j) ? a[e] * a[e] : 0.0;
+                if (r == j) red[QP_WAVES] = a[e];
+            }
+            // its squared norm over rows >= j, from scratch, and element j (block reduction in fixed order)
+            sq = wave_sum(sq);
+            if (lane == 0) red[wave] = sq;
+            // row j of the earlier reflectors of the panel (needed for the row update below)
+            if (tid < QP_NB) aux[QP_NB + tid] = tid < k ? A[j + (long)n * (j0 + tid)] : 0.0;
+            __syncthreads();
+            double maxval = 0.0;
+#pragma unroll
+            for (int w2 = 0; w2 < QP_WAVES; ++w2) maxval += red[w2];
+            const double xi1 = red[QP_WAVES];
+            // ---- reflector (UDT.jl:133-148)
+            double tj = 0.0, nu = 0.0, xi = 1.0;
+            if (maxval != 0.0) {
+                nu = copysign(sqrt(maxval), xi1);
+                xi = xi1 + nu;
+                tj = xi / nu;
+            }
+#pragma unroll
+            for (int e = 0; e < QP_RPT; ++e) {
+                const int r = tid + QP_THREADS * e;
+                if (r < n) {
+                    double vr = (r == j) ? 1.0 : 0.0;
+                    if (r >= j) {
+                        double newj = a[e];
+                        if (maxval != 0.0) {
+                            if (r == j) newj = -nu;
+                            else { newj = a[e] / xi; vr = newj; }
+                        }
+                        A[r + (long)n * j] = newj;
+                    }
+                    v[r] = vr;
+                }
+            }
+            if (tid == 0) tau[j] = tj;
+            __syncthreads();
+            // ---- F[k][c] = tau A[j:, c]' v for the trailing columns c > j: the ONE pass over the trailing matrix.
+            // Every request of a column group goes out before the first product (clamped addresses, no predicates).
+            double vq[QMAX];
+#pragma unroll
+            for (int q = 0; q < QMAX; ++q) {
+                const int rr = j + lane + 64 * q;
+                vq[q] = rr < n ? v[min(rr, n - 1)] : 0.0;
+            }
+            // (the pass starts at the panel's first column: for c < j the same product is aux[c - j0] = -tau V[:, c]' v,
+            // and lane 0 of the first row block holds A[j, c], which the row update below needs)
+            for (int c0 = j0 + wave * QP_UC; c0 < n; c0 += QP_WAVES * QP_UC) {
+                double xa[QP_UC][QMAX];
+#pragma unroll
+                for (int u = 0; u < QP_UC; ++u) {
+                    const double *__restrict__ col = A + (long)n * min(c0 + u, n - 1);
+#pragma unroll
+                    for (int q = 0; q < QMAX; ++q) xa[u][q] = col[min(j + lane + 64 * q, n - 1)];
+                }
+#pragma unroll
+                for (int u = 0; u < QP_UC; ++u) {
+                    double d = 0.0;
+#pragma unroll
+                    for (int q = 0; q < QMAX; ++q) d += vq[q] * xa[u][q];
+                    d = wave_sum(d);
+                    const int c = c0 + u;
+                    if (lane == 0 && c < n) {
+                        if (c > j) { F[k * n + c] = tj * d; rowj[c] = xa[u][0]; }
+                        else if (c < j) aux[c - j0] = -tj * d;
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- F[:, k] += F[:, 0:k] aux; row j of the trailing matrix (= row j of R); norm down-dating
+            for (int c = j + 1 + tid; c < n; c += QP_THREADS) {
+                double f = F[k * n + c], s2 = 0.0;
+                const double ajc = rowj[c];
+#pragma unroll
+                for (int kk = 0; kk < QP_NB; ++kk) {
+                    const double fk = kk < k ? F[kk * n + c] : 0.0;
+                    f += fk * aux[kk];
+                    s2 += fk * aux[QP_NB + kk];
+                }
+                F[k * n + c] = f;
+                const double rjc = ajc - f - s2;  // v[j] = 1
+                A[j + (long)n * c] = rjc;
+                const double t = vn1[c] - rjc * rjc;
+                if (t <= 1e-4 * vn2[c]) todo[1 + atomicAdd(&todo[0], 1)] = c;  // cancellation: take it from scratch
+                else vn1[c] = t;
+            }
+            __syncthreads();
+            // ---- exact norms of the flagged columns, from the virtually updated column
+            const int ntodo = todo[0];
+            for (int i = wave; i < ntodo; i += QP_WAVES) {
+                const int c = todo[1 + i];
+                double sacc = 0.0;
+                for (int rr = j + 1 + lane; rr < n; rr += 64) {
+                    double x = A[rr + (long)n * c];
+                    for (int kk = 0; kk <= k; ++kk) x -= A[rr + (long)n * (j0 + kk)] * F[kk * n + c];
+                    sacc += x * x;
+                }
+                sacc = wave_sum(sacc);
+                if (lane == 0) { vn1[c] = sacc; vn2[c] = sacc; }
+            }
+            if (ntodo) {
+                __syncthreads();
+                if (tid == 0) todo[0] = 0;
+                __syncthreads();
+            }
+        }
+        // ---- rank-kb update of the trailing matrix below / right of the panel: A[r, c] -= V[r, :] F[:, c]
+        const int jn = j0 + kb;
+        if (jn < n) {
+            for (int c0 = jn + wave * QP_UC2; c0 < n; c0 += QP_WAVES * QP_UC2) {
+                // (1024 threads = 4 waves per SIMD = 128 VGPRs per lane: the panel's F entries come from LDS as
+                // broadcast reads instead of sitting in registers)
+                double x[QP_UC2][QMAX];
+#pragma unroll
+                for (int u = 0; u < QP_UC2; ++u) {
+                    const double *__restrict__ col = A + (long)n * min(c0 + u, n - 1);
+#pragma unroll
+                    for (int q = 0; q < QMAX; ++q) x[u][q] = col[min(jn + lane + 64 * q, n - 1)];
+                }
+#pragma unroll 4
+                for (int kk = 0; kk < kb; ++kk) {
+                    const double *__restrict__ vc = A + (long)n * (j0 + kk);
+                    double vk[QMAX];
+#pragma unroll
+                    for (int q = 0; q < QMAX; ++q) vk[q] = vc[min(jn + lane + 64 * q, n - 1)];
+#pragma unroll
+                    for (int u = 0; u < QP_UC2; ++u) {
+                        const double fk = F[kk * n + min(c0 + u, n - 1)];
+#pragma unroll
+                        for (int q = 0; q < QMAX; ++q) x[u][q] -= vk[q] * fk;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < QP_UC2; ++u)
+#pragma unroll
+                    for (int q = 0; q < QMAX; ++q) {
+                        const int rr = jn + lane + 64 * q;
+                        if (rr < n && c0 + u < n) A[rr + (long)n * (c0 + u)] = x[u][q];
+                    }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
 // On-chip variant for 128 < n <= 256: one workgroup of 512 threads (8 waves) keeps the matrix
 // next to the ALUs for the whole factorisation, so a step costs FMAs and LDS broadcasts instead
 // of an L2 round trip per trailing element.
@@ -1411,6 +1675,21 @@ static hipError_t launch_qr_single(int n, int n_units, double *A, long strideA, 
         if (e != hipSuccess || !two_phase) return e;
         hipLaunchKernelGGL((qr_tail_kernel<128, 4>), dim3(n_units), dim3(256), 0, s, n_units, X, strideX, A, strideA, tau, pivot,
                            never, -1);
+        return hipGetLastError();
+    }
+    // n > 256: the panel (dlaqps-style) kernel, unless it is switched off or its LDS does not fit
+    if (n > 256 && n <= 768 && !no_tile && !guard && !src && getenv("DQMC_QR_NOPANEL") == nullptr) {
+        const size_t lds_p = ((size_t)(QP_NB + 4) * n + 2 * QP_NB + QP_WAVES + 2) * sizeof(double) + (size_t)(n + 1) * sizeof(int);
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        static unsigned pmask = 0;
+        if (!(pmask & (1u << dev))) {
+            (void)hipFuncSetAttribute((const void *)qr_panel_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            (void)hipFuncSetAttribute((const void *)qr_panel_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            pmask |= 1u << dev;
+        }
+        if (n <= 576) hipLaunchKernelGGL((qr_panel_kernel<9>), dim3(n_units), dim3(QP_THREADS), lds_p, s, n, A, strideA, tau, pivot);
+        else hipLaunchKernelGGL((qr_panel_kernel<12>), dim3(n_units), dim3(QP_THREADS), lds_p, s, n, A, strideA, tau, pivot);
         return hipGetLastError();
     }
     const size_t lds = 2 * 1024 * sizeof(double);

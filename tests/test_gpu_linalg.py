@@ -59,6 +59,46 @@ def test_udt_contracts(gpu, O, n, apply_pivot):
             assert relerr(U[i], Uo) < 1e-9
 
 
+@pytest.mark.parametrize("n,batch", [(320, 3), (576, 2), (600, 1)])
+def test_udt_panel_kernel_n_above_256(gpu, O, n, batch):
+    """n > 256: the panel (dlaqps-style) QR - one read of the trailing matrix per step, norms down-dated with the row of R
+    and recomputed on cancellation - against the contracts of test/slice_matrices.jl:202-234, against the oracle's
+    decomposition (same pivots unless a near-tie flips, same D) and against the streaming kernel it replaces
+    (DQMC_QR_NOPANEL: the reference's from-scratch norms)"""
+    import os
+    rng = np.random.default_rng(n)
+    X = rng.standard_normal((batch, n, n))
+    X[0] *= np.exp(rng.uniform(-20, 20, size=n))[None, :]      # graded columns as in a DQMC chain
+    if batch > 1:
+        X[1] = X[1] @ np.diag(np.exp(np.linspace(15, -15, n))) @ rng.standard_normal((n, n)) / n  # graded, mixed
+    for apply_pivot in (True, False):
+        U, D, T, piv = gpu.udt_AVX_pivot(X, apply_pivot)
+        os.environ["DQMC_QR_NOPANEL"] = "1"
+        try:
+            U0, D0, T0, piv0 = gpu.udt_AVX_pivot(X, apply_pivot)
+        finally:
+            del os.environ["DQMC_QR_NOPANEL"]
+        for i in range(batch):
+            assert relerr(U[i].T @ U[i], np.eye(n)) < 1e-12
+            assert np.all(D[i] > 0) and np.all(np.diff(D[i]) <= 1e-9 * D[i][:-1])
+            assert sorted(piv[i]) == list(range(1, n + 1))
+            if apply_pivot:
+                rec = (U[i] * D[i]) @ T[i]
+            else:
+                P = np.zeros((n, n)); P[np.arange(n), piv[i] - 1] = 1
+                rec = (U[i] * D[i]) @ np.triu(T[i]) @ P
+            scale = np.abs(X[i]).max(axis=0)
+            assert (np.abs(rec - X[i]) / scale[None, :]).max() < 1e-11
+            if np.array_equal(piv[i], piv0[i]):
+                assert relerr(D[i], D0[i]) < 1e-10
+            else:  # a near-tie went the other way: D is still the same to the size of the tie
+                assert np.abs(np.log(D[i] / D0[i])).max() < 1e-6
+        if n <= 320 and apply_pivot:
+            Uo, Do, To, po = O.udt_pivot(X[0], True)
+            if np.array_equal(po, piv[0]):
+                assert relerr(D[0], Do) < 1e-10
+
+
 def test_two_phase_qr_against_cooperative_alone(gpu):
     """n = 256: 128 cooperative steps + qr_tail_kernel (one CU per matrix, last 64 steps one column per lane)
     against the cooperative kernel factoring everything (DQMC_QR_TAIL=0): same pivots, same factors up to rounding"""
