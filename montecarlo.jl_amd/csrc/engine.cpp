@@ -78,6 +78,9 @@ struct dqmc_handle {
     double *sU = nullptr, *sVT = nullptr;
     double *greens_alt = nullptr, *lu_img = nullptr;  // decide / apply sweep (sweep_lu.hip)
     bool sweep_lu = true, sweep_fused = true;
+    bool sweep_persist = false;        // one launch per time slice (sweep_slice_kernel)
+    unsigned *slice_flags = nullptr;   // its hand-over words
+    unsigned slice_launch = 0;         // launches so far (the tags grow monotonically)
     WalkerRng *rng = nullptr;
     DevStats *stats = nullptr;
     unsigned long long *pc_scratch = nullptr;  // prop_check_kernel: partial maximum + arrival counter per walker
@@ -340,7 +343,10 @@ static int check_qr_workspace(dqmc_handle *h)
     HIPCHK(hipMemcpy(&e, h->qr_ws.errflag, sizeof(int), hipMemcpyDeviceToHost));
     if (e) {  // reported once: the flag is cleared, the data of the failed call is not trustworthy
         HIPCHK(hipMemset(h->qr_ws.errflag, 0, sizeof(int)));
-        return fail(h, DQMC_ERR_HIP, "sweep elimination: hand-off timed out (results of this call are invalid)");
+        return fail(h, DQMC_ERR_HIP, (e & 8) ? "site sweep (one launch per slice): a hand-over between workgroups timed out - the grid was "
+                                               "not co-resident (results of this call are invalid; the default launch-per-chunk form has no "
+                                               "such requirement)"
+                                             : "sweep elimination: hand-off timed out (results of this call are invalid)");
     }
     return 0;
 }
@@ -838,6 +844,18 @@ static int sweep_spatial_launches(dqmc_handle *h)
         const size_t istr = (size_t)h->units * sweep_lu_image_doubles();
         const long cstr = (long)h->N * h->M;
         hipEvent_t a, b;
+        if (h->sweep_persist) {
+            // the whole slice in one launch: chunks back to back, tagged hand-overs between the elimination and the
+            // flush workgroups (sweep_lu.hip)
+            timing_events(h, &a, &b);
+            h->slice_launch += 1;
+            HIPCHK(launch_sweep_slice(h->n, h->nb, h->W, h->greens, h->greens_alt, h->nn, cslice, cstr, h->lu_img, (long)istr,
+                                      h->sc, h->rng, h->stats, h->p.check_sign_problem, h->qr_ws.errflag, h->slice_flags,
+                                      h->slice_launch, h->cur, a, b));
+            CHK(timing_push(h, a, b, DQMC_K_SWEEP));
+            if ((h->n / 64) & 1) std::swap(h->greens, h->greens_alt);
+            return 0;
+        }
         if (h->sweep_fused && h->n % 64 == 0 && h->N >= 128) {
             // the elimination of chunk c runs beside the flush of chunk c - 1 (one launch per chunk boundary)
             const int nc = h->N / 64;
@@ -1074,6 +1092,19 @@ int dqmc_create(const dqmc_params *p, dqmc_handle **out)
     CCHK(dalloc(h, &h->sVT, (size_t)h->units * h->n * h->kd));
     CCHK(dalloc(h, &h->greens_alt, un));
     CCHK(dalloc(h, &h->lu_img, 2 * (size_t)h->units * sweep_lu_image_doubles()));
+    // DQMC_SWEEP_PERSIST=1: one launch per time slice (sweep_slice_kernel: the elimination workgroup runs its chunks back
+    // to back, tagged hand-overs to and from the flush workgroups).  Built and parity-tested in round 3, measured at
+    // config 3: 143.9 us per slice against 137 us for the five launches it replaces (with memory-model fences: 214 us) -
+    // in-kernel stamps show the same 8.5 us from the start of a chunk to its first decision as in the launch-per-chunk
+    // form (that time is instruction issue and L2 latency of the prologue, not the HBM misses behind a kernel boundary),
+    // so the launch gaps it saves are smaller than the hand-overs it adds.  Off by default.
+    {
+        const char *e = getenv("DQMC_SWEEP_PERSIST");
+        if (h->sweep_lu && h->sweep_fused && h->n % 256 == 0 && h->n <= 512 && e && atoi(e) != 0) {
+            CCHK(dalloc(h, &h->slice_flags, sweep_slice_flag_words(h->W, h->units)));
+            h->sweep_persist = true;
+        }
+    }
     CCHK(dalloc(h, &h->rng, (size_t)h->W));
     CCHK(dalloc(h, &h->stats, (size_t)h->W));
     CCHK(dalloc(h, &h->pc_scratch, 2 * (size_t)h->W));

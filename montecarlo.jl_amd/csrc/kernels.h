@@ -221,6 +221,14 @@ hipError_t launch_sweep_fused(int n, int nb, int n_walkers, const double *Gin, d
                               int8_t *conf_slice, long conf_stride, int site0, int site0p, double *img,
                               const double *imgp, SweepConsts sc, WalkerRng *rng, DevStats *stats, int check_sign,
                               int *errflag, hipStream_t s, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
+// the whole site sweep of one time slice in ONE launch (n % 256 == 0; the grid - n_walkers + 4 n_units workgroups at
+// n = 256 - must be co-resident): chunks back to back with tagged hand-overs between the elimination and the flush
+// workgroups; the result is in G0 (n / 64 even) or G1
+size_t sweep_slice_flag_words(int n_walkers, int n_units);
+hipError_t launch_sweep_slice(int n, int nb, int n_walkers, double *G0, double *G1, long strideG, int8_t *conf_slice,
+                              long conf_stride, double *img, long istr, SweepConsts sc, WalkerRng *rng, DevStats *stats,
+                              int check_sign, int *errflag, unsigned *flags, unsigned launch, hipStream_t s,
+                              hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
 hipError_t launch_sweep_flush_lu(int n, int n_units, const double *Gin, double *Gout, long strideG, int site0,
                                  int nsites, const double *img, hipStream_t s, hipEvent_t start = nullptr,
                                  hipEvent_t stop = nullptr);

@@ -1139,6 +1139,215 @@ __global__ __launch_bounds__(256) void sweep_fused_kernel(SweepFusedArgs a)
                                      a.imgp, a.tiles_m, a.tiles_n);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// One launch per time slice (round 3): the elimination workgroup of a walker runs its chunks back to back, the flush
+// workgroups of its units apply chunk after chunk, and the two kinds hand over through tagged words in global memory:
+//   E(c) needs F(c - 2) complete for its units (its prologue reads the Green's function with chunks <= c - 2 applied:
+//        the buffer F(c - 1) reads), in steady state long done;
+//   F(c) needs the images of E(c) and every flush workgroup of its unit done with F(c - 1).
+// What this removes from every chunk boundary of the launch-per-chunk form: the launch gap and kernel exit, the
+// dependent HBM read of the walker's RNG record, and - the kernel boundary no longer invalidates the caches - the HBM
+// round trip of the prologue's operands (they come from L2).  Data crosses workgroups under agent-scope release /
+// acquire fences around the flag words (HIP memory model), or - placement permitting - under the lighter pair below.
+// Every wait is bounded, so that a grid that is not co-resident (CUs held by another
+// process) is noticed: all workgroups then leave, *errflag bit 3 is raised and the host reports the call as failed.
+// Selected with DQMC_SWEEP_PERSIST=1 (measured slower than the launch-per-chunk form, see engine.cpp: off by default).
+struct SweepSliceArgs {
+    int n, n_walkers, n_units, nc;
+    double *G0, *G1;            // chunk c: flush reads G(c & 1), writes the other; the result of the slice is in G(nc & 1)
+    long strideG;
+    int8_t *conf_slice;
+    long conf_stride;
+    double *img;                // two image sets: img + (c & 1) * istr
+    long istr;
+    SweepConsts sc;
+    WalkerRng *rngs;
+    DevStats *stats;
+    int check_sign;
+    int *errflag;
+    int tiles_m, tiles_n;
+    unsigned *flags;            // [0] arrivals; [16 + 8 w + c] E(c) of walker w done (tag); [16 + 8 W + 8 u + c] flush workgroups of unit u done with chunk c
+    unsigned launch;            // launch counter of this handle (tags grow monotonically: no reset between launches)
+    int grid_wgs;               // workgroups that take part in the arrival handshake
+    int force_agent;            // DQMC_SLICE_AGENT: memory-model fences regardless of placement
+};
+constexpr int SL_SPIN = 1 << 22;
+// Release / acquire around the hand-over words.  The memory-model form (agent scope) writes the XCD's whole L2 back and
+// invalidates it - on a part with eight L2s that is what makes workgroups of different XCDs see each other's data, but
+// here it would throw away exactly what the one-launch form is for (measured: 214 us per slice against 137 for the
+// launch-per-chunk form).  When the elimination workgroup of a walker and the flush workgroups of its unit have
+// verified at run time (HW_REG_XCC_ID, exchanged during the arrival handshake) that they all sit on ONE XCD, they
+// share that XCD's L2: the writer only has to wait until its stores are in L2 (the vector L1 is write-through:
+// s_waitcnt vmcnt(0)), the reader only has to drop its own L1 (buffer_inv sc0).  Same hardware-behaviour dependency
+// as the cooperative QR's L2-resident mailbox; any other placement takes the agent-scope fences.
+__device__ __forceinline__ void sl_release(bool same_xcd)
+{
+    if (same_xcd) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+}
+__device__ __forceinline__ void sl_acquire(bool same_xcd)
+{
+    if (same_xcd) asm volatile("buffer_inv sc0" ::: "memory");
+    else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+// thread 0 waits until *p >= target (agent scope), everybody leaves through a barrier and the acquire;
+// returns false on time-out / abort
+__device__ __forceinline__ bool sl_wait_ge(unsigned *p, unsigned target, int *abort_lds, bool same_xcd)
+{
+    if (threadIdx.x == 0) {
+        int ok = 0;
+        for (int it = 0; it < SL_SPIN; ++it) {
+            if ((int)(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0) { ok = 1; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (!ok) *abort_lds = 1;
+    }
+    __syncthreads();
+    sl_acquire(same_xcd);
+    return *abort_lds == 0;
+}
+template <int NB, int NT, int NCP>
+__global__ __launch_bounds__(256) void sweep_slice_kernel(SweepSliceArgs a)
+{
+    __shared__ int s_abort, s_same;
+    const int tid = threadIdx.x;
+    if (tid == 0) { s_abort = 0; s_same = 0; }
+    __syncthreads();
+    const bool elim = (int)blockIdx.x < a.n_walkers;
+    const int fbid = (int)blockIdx.x - a.n_walkers;
+    const int T = a.tiles_m * a.tiles_n;
+    const int unit = elim ? (int)blockIdx.x * NB : ((fbid >> 3) / T) * 8 + (fbid & 7);
+    if (!elim && unit >= a.n_units) return;  // padding workgroups of the XCD-aware map: never part of anything
+    unsigned *Edone = a.flags + 16, *Fdone = Edone + 8 * a.n_walkers, *xcc = Fdone + 8 * (((a.n_units + 7) / 8) * 8);
+    // ---- every workgroup leaves its XCC id behind; a walker's workgroups compare them when they first need to know
+    // (no launch-wide handshake: the dispatcher takes ~15 us to start the last of the 160 workgroups, and the first
+    // elimination must not wait for that)
+    if (tid == 0) {
+        const unsigned my = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 0xfu;  // HW_REG_XCC_ID[3:0]
+        __hip_atomic_store(&xcc[blockIdx.x], a.launch * 16u + my, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    auto placement = [&]() -> bool {  // false: a workgroup of this walker never showed up (bounded wait)
+        if (tid == 0) {
+            const int w = unit / NB, g8 = unit >> 3;
+            bool same = NB == 1 && !a.force_agent, all = true;
+            unsigned ref = 0;
+            for (int i = 0; i <= T && all; ++i) {
+                const int idx = i == 0 ? w : a.n_walkers + (((g8 * T + (i - 1)) << 3) | (unit & 7));
+                unsigned v = 0;
+                int it = 0;
+                for (; it < SL_SPIN; ++it) {
+                    v = __hip_atomic_load(&xcc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((v >> 4) == a.launch) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (it == SL_SPIN) all = false;
+                if (i == 0) ref = v;
+                else same = same && v == ref;
+            }
+            s_same = (all && same) ? 1 : 0;
+            if (!all) s_abort = 1;
+        }
+        __syncthreads();
+        return s_abort == 0;
+    };
+    bool same_xcd = false;
+    if (elim) {
+        const int w = blockIdx.x;
+        for (int c = 0; c < a.nc; ++c) {
+            if (c >= 2)
+                for (int b = 0; b < NB; ++b)
+                    if (!sl_wait_ge(&Fdone[8 * (w * NB + b) + (c - 2)], a.launch * (unsigned)T, &s_abort, same_xcd)) {
+                        if (tid == 0) atomicOr(a.errflag, 8);
+                        return;
+                    }
+            const double *Gin = ((c - 1) & 1) ? a.G1 : a.G0;  // c == 0: G0
+            double *img = a.img + (long)(c & 1) * a.istr;
+            const double *imgp = a.img + (long)((c - 1) & 1) * a.istr;
+            if (c == 0)
+                lu4_block<NB, true, false>(w, a.n, a.G0, a.strideG, a.conf_slice, a.conf_stride, 0, 64, img, a.sc, a.rngs,
+                                           a.stats, a.check_sign, a.errflag, 0, nullptr);
+            else
+                lu4_block<NB, true, true>(w, a.n, Gin, a.strideG, a.conf_slice, a.conf_stride, 64 * c, 64, img, a.sc, a.rngs,
+                                          a.stats, a.check_sign, a.errflag, 64 * (c - 1), imgp);
+            if (c == 0) {
+                if (!placement()) {
+                    if (tid == 0) atomicOr(a.errflag, 8);
+                    return;
+                }
+                same_xcd = s_same != 0;
+            }
+            sl_release(same_xcd);
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(&Edone[8 * w + c], a.launch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sl_acquire(same_xcd);  // (my own RNG record / counters / images of the next chunk)
+        }
+    } else {
+        const int w = unit / NB;
+        if (!placement()) {
+            if (tid == 0) atomicOr(a.errflag, 8);
+            return;
+        }
+        same_xcd = s_same != 0;
+        for (int c = 0; c < a.nc; ++c) {
+            bool ok = sl_wait_ge(&Edone[8 * w + c], a.launch, &s_abort, same_xcd);
+            if (ok && c >= 1) ok = sl_wait_ge(&Fdone[8 * unit + (c - 1)], a.launch * (unsigned)T, &s_abort, same_xcd);
+            if (!ok) {
+                if (tid == 0) atomicOr(a.errflag, 8);
+                return;
+            }
+            const double *Gin = (c & 1) ? a.G1 : a.G0;
+            double *Gout = (c & 1) ? a.G0 : a.G1;
+            flush_lu_body<true, NT, NCP>(fbid, a.n, a.n_units, Gin, Gout, a.strideG, 64 * c, 64,
+                                         a.img + (long)(c & 1) * a.istr, a.tiles_m, a.tiles_n);
+            sl_release(same_xcd);
+            __syncthreads();
+            if (tid == 0) __hip_atomic_fetch_add(&Fdone[8 * unit + c], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// flags: [16][8 per walker][8 per unit, units rounded up to 8][one per workgroup of the grid]: zero-initialised once
+size_t sweep_slice_flag_words(int n_walkers, int n_units)
+{
+    const size_t u8 = (size_t)((n_units + 7) / 8) * 8;
+    return 16 + 8 * (size_t)n_walkers + 8 * u8 + (size_t)n_walkers + u8 * 64;
+}
+hipError_t launch_sweep_slice(int n, int nb, int n_walkers, double *G0, double *G1, long strideG, int8_t *conf_slice,
+                              long conf_stride, double *img, long istr, SweepConsts sc, WalkerRng *rng, DevStats *stats,
+                              int check_sign, int *errflag, unsigned *flags, unsigned launch, hipStream_t s,
+                              hipEvent_t start, hipEvent_t stop)
+{
+    if (n % 256 != 0 || n / 64 > 8 || nb < 1 || nb > 2) return hipErrorInvalidValue;
+    const int n_units = n_walkers * nb;
+    SweepSliceArgs a;
+    a.n = n; a.n_walkers = n_walkers; a.n_units = n_units; a.nc = n / 64;
+    a.G0 = G0; a.G1 = G1; a.strideG = strideG; a.conf_slice = conf_slice; a.conf_stride = conf_stride;
+    a.img = img; a.istr = istr; a.sc = sc; a.rngs = rng; a.stats = stats; a.check_sign = check_sign; a.errflag = errflag;
+    a.tiles_m = n / 64; a.tiles_n = n / (16 * 8 * 2);  // NT = 8, two column passes per flush workgroup
+    a.flags = flags; a.launch = launch;
+    a.force_agent = getenv("DQMC_SLICE_AGENT") != nullptr;
+    const int groups = (n_units + 7) / 8;
+    const int flush_blocks = groups * 8 * a.tiles_m * a.tiles_n;
+    a.grid_wgs = n_walkers + n_units * a.tiles_m * a.tiles_n;  // (the padding workgroups leave before the handshake)
+    const size_t lds_flush = ((size_t)LU_STRIDE + 16 * 8 * FL_LDR) * sizeof(double);
+    const size_t lds_lu = nb == 1 ? sizeof(Lu4Smem<1>) : sizeof(Lu4Smem<2>);
+    const size_t lds_pro = nb == 1 ? (sizeof(Lu4Smem<1>) + 15) / 16 * 16 + (LU_STRIDE + 1536 + 1024 + 8) * sizeof(double) : lds_lu;
+    const size_t lds_e = lds_pro > lds_lu ? lds_pro : lds_lu;
+    const size_t lds = lds_flush > lds_e ? lds_flush : lds_e;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    static unsigned attr_mask = 0;
+    if (!(attr_mask & (1u << dev))) {
+        (void)hipFuncSetAttribute((const void *)sweep_slice_kernel<1, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute((const void *)sweep_slice_kernel<2, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        attr_mask |= 1u << dev;
+    }
+    dim3 grid(n_walkers + flush_blocks), block(256);
+    if (nb == 1) hipExtLaunchKernelGGL((sweep_slice_kernel<1, 8, 2>), grid, block, lds, s, start, stop, 0, a);
+    else hipExtLaunchKernelGGL((sweep_slice_kernel<2, 8, 2>), grid, block, lds, s, start, stop, 0, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_sweep_flush_lu(int n, int n_units, const double *Gin, double *Gout, long strideG, int site0,
                                  int nsites, const double *img, hipStream_t s, hipEvent_t start, hipEvent_t stop)
 {
