@@ -155,8 +155,9 @@ def test_magnitude_stats_events(gpu, O, kind, L, beta):
         assert sum(mc.analysis(w).negative_probability.count for w in range(nw)) >= 2
     else:  # the attractive ratio is a square (Attractive.jl:113-127): never negative
         assert all(mc.analysis(w).negative_probability.count == 0 for w in range(nw))
-    # (3) through the lower turn-around and up to the first stabilisation of the up pass (stack.jl:519-550): the
-    # damaged G is seen by the check of the next recomputation, a second perturbation by the one after
+    # (3) through the lower turn-around - which recomputes G without a check (stack.jl:506-517), so the damage of (2)
+    # leaves no event of its own there - and up to the first stabilisation of the up pass (stack.jl:519-550), which sees a
+    # second perturbation (through the wrap of the old G, stack.jl:534-536)
     both(mc.p.safe_mult)
     _inject(mc, refs, lambda w, bl: [b + 1e-3 * noise[w][i].T for i, b in enumerate(bl)])
     both(2 * mc.p.slices - 3 - 2 * mc.p.safe_mult - 1)
@@ -227,3 +228,29 @@ def test_val_false_behind_in_place_factorisations(gpu, n, batch):
         rec = (U[i] * D[i]) @ np.triu(T[i]) @ P
         scale = np.abs(X[i]).max(axis=0)
         assert (np.abs(rec - X[i]) / scale[None, :]).max() < 1e-12
+
+
+@pytest.mark.parametrize("kind,L,beta", [("attractive", 8, 2.0), ("repulsive", 16, 2.0)])
+def test_checks_switched_off(gpu, O, kind, L, beta):
+    """check_propagation_error = check_sign_problem = false (DQMCParameters, DQMC.jl:77-78): the stabilisation steps
+    skip the wrap of the old Green's function and the comparison (stack.jl:534-549, 596-612), sweep_spatial the sign
+    bookkeeping (DQMC.jl:554-569) - same trajectory as the oracle with the same switches, no events recorded"""
+    mc, refs = make_pair(gpu, O, L, kind, beta, n_walkers=2, check_propagation_error=False, check_sign_problem=False)
+    refs = []
+    for w in range(2):
+        mk = {"mu": mc.model.mu} if kind == "attractive" else {}
+        o = O.OracleDQMC(L, kind, beta=beta, delta_tau=mc.p.delta_tau, safe_mult=mc.p.safe_mult, U=mc.model.U,
+                         check_propagation_error=False, check_sign_problem=False, **mk)
+        o.set_conf(mc.conf(w)); o.seed(mc.seeds[w])
+        refs.append(o)
+    mc.prepare()
+    _oracles(refs, lambda o: o.prepare())
+    compare(mc, refs)
+    mc.sweep(1)
+    _oracles(refs, lambda o: o.sweeps(1))
+    compare(mc, refs)
+    _counters_equal(mc, refs)
+    for w in range(2):
+        a = mc.analysis(w)
+        assert a.propagation_error.count == 0 and a.negative_probability.count == 0
+    mc.close()
