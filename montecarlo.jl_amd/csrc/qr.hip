@@ -207,9 +207,13 @@ constexpr int QP_UC2 = 4;  // columns per group in the rank-QP_NB update
 constexpr int QP_THREADS = 512, QP_WAVES = QP_THREADS / 64;  // 2 waves per SIMD: 256 VGPRs per lane (at 1024 threads the
                                                              // 128-register budget spilled and the kernel ran 2.4 x slower)
 constexpr int QP_RPT = 2;  // rows per thread in the one-element-per-row phases (n <= 1024)
+// barrier that hands over LDS data only (the global stores of the step stay in flight; the one full barrier of a step
+// sits behind the row update, before the next step touches what this one stored)
+#define QP_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 template <int QMAX>
 __global__ __launch_bounds__(QP_THREADS) void qr_panel_kernel(int n, double *__restrict__ Aall, long strideA,
-                                                             double *__restrict__ tauall, int *__restrict__ pivall)
+                                                             double *__restrict__ tauall, int *__restrict__ pivall,
+                                                             double thr)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double *F = sm;                  // [QP_NB][n]: F[kk * n + c]
@@ -219,8 +223,8 @@ __global__ __launch_bounds__(QP_THREADS) void qr_panel_kernel(int n, double *__r
     double *rowj = v + n;            // row j of the trailing matrix as the pass over it found it
     double *aux = rowj + n;          // [2 QP_NB]: aux of the F update, row j of the panel's reflectors
     double *red = aux + 2 * QP_NB;   // [QP_WAVES + 2]
-    int *todo = reinterpret_cast<int *>(red + QP_WAVES + 2);  // columns whose norm must be recomputed, [0] = count
-    __shared__ int s_jm;
+    int *pvw = reinterpret_cast<int *>(red + QP_WAVES + 2);   // [QP_WAVES] per-wave pivot candidates
+    int *todo = pvw + QP_WAVES;      // columns whose norm must be recomputed, [0] = count
 
     const int unit = blockIdx.x;
     double *__restrict__ A = Aall + (long)unit * strideA;
@@ -247,11 +251,12 @@ __global__ __launch_bounds__(QP_THREADS) void qr_panel_kernel(int n, double *__r
         __syncthreads();
         for (int k = 0; k < kb; ++k) {
             const int j = j0 + k;
-            // ---- pivot: first maximum of the trailing column norms (UDT.jl:151-168)
-            if (wave == 0) {
+            // ---- pivot: first maximum of the trailing column norms (UDT.jl:151-168); every wave scans a stripe, the
+            // eight partial results meet in LDS and every thread finishes the search for itself
+            {
                 double best = -1.0;
                 int bi = 0x7fffffff;
-                for (int c = j + lane; c < n; c += 64) {
+                for (int c = j + tid; c < n; c += QP_THREADS) {
                     const double val = vn1[c];
                     if (val > best) { best = val; bi = c; }
                 }
@@ -261,17 +266,51 @@ __global__ __launch_bounds__(QP_THREADS) void qr_panel_kernel(int n, double *__r
                     const int oi = __shfl_xor(bi, off, 64);
                     if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
                 }
-                if (lane == 0) s_jm = (bi < n) ? bi : j;
+                if (lane == 0) { red[wave] = best; pvw[wave] = bi; }
             }
-            __syncthreads();
-            const int jm = s_jm;
-            // ---- swap columns j <-> jm (UDT.jl:219-231) together with their rows of F and their norms
-            if (jm != j) {
-                for (int rr = tid; rr < n; rr += QP_THREADS) {
-                    const double a = A[rr + (long)n * jm], b = A[rr + (long)n * j];
-                    A[rr + (long)n * j] = a;
-                    A[rr + (long)n * jm] = b;
+            QP_LDS_BARRIER();
+            int jm;
+            {
+                double best = red[0];
+                int bi = pvw[0];
+#pragma unroll
+                for (int w2 = 1; w2 < QP_WAVES; ++w2) {
+                    const double ov = red[w2];
+                    const int oi = pvw[w2];
+                    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
                 }
+                jm = (bi < n) ? bi : j;
+            }
+            // ---- the pivot column (now at position jm) comes into registers, is brought up to date with the reflectors
+            // of this panel (rows >= j) and goes to position j; the column that was there goes to jm whole - the swap of
+            // UDT.jl:219-231 without a pass of its own.  (All loops over the panel run over the compile-time QP_NB with
+            // clamped addresses and zero coefficients: a run-time trip count, or a predicate on a load, turns sixteen
+            // independent requests into sixteen round trips.)
+            double a[QP_RPT], bold[QP_RPT];
+            double sq = 0.0;
+            double fj[QP_NB];
+#pragma unroll
+            for (int kk = 0; kk < QP_NB; ++kk) fj[kk] = kk < k ? F[kk * n + jm] : 0.0;
+#pragma unroll
+            for (int e = 0; e < QP_RPT; ++e) {
+                const int r = tid + QP_THREADS * e, rc = min(r, n - 1);
+                a[e] = A[rc + (long)n * jm];
+                bold[e] = A[rc + (long)n * j];
+                double vp[QP_NB];
+#pragma unroll
+                for (int kk = 0; kk < QP_NB; ++kk) vp[kk] = A[rc + (long)n * (j0 + min(kk, kb - 1))];
+#pragma unroll
+                for (int kk = 0; kk < QP_NB; ++kk) a[e] -= (r >= j ? fj[kk] : 0.0) * vp[kk];
+                sq += (r < n && r >= j) ? a[e] * a[e] : 0.0;
+            }
+            QP_LDS_BARRIER();  // (everybody has read red[] / pvw[] / F[., jm])
+#pragma unroll
+            for (int e = 0; e < QP_RPT; ++e)
+                if (tid + QP_THREADS * e == j) red[QP_WAVES] = a[e];
+            // its squared norm over rows >= j, from scratch, and element j (block reduction in fixed order)
+            sq = wave_sum(sq);
+            if (lane == 0) red[wave] = sq;
+            if (jm != j) {
                 if (tid < kb) {
                     const double fa = F[tid * n + jm], fb = F[tid * n + j];
                     F[tid * n + j] = fa;
@@ -281,28 +320,12 @@ __global__ __launch_bounds__(QP_THREADS) void qr_panel_kernel(int n, double *__r
                     vn1[jm] = vn1[j]; vn2[jm] = vn2[j];
                     const int t = piv[j]; piv[j] = piv[jm]; piv[jm] = t;
                 }
+#pragma unroll
+                for (int e = 0; e < QP_RPT; ++e) {
+                    const int r = tid + QP_THREADS * e;
+                    if (r < n) A[r + (long)n * jm] = bold[e];
+                }
             }
-            __syncthreads();
-            // ---- the pivot column, rows >= j, brought up to date with the reflectors of this panel.  (All loops over
-            // the panel run over the compile-time QP_NB with clamped addresses and zero coefficients: a run-time trip
-            // count, or a predicate on a load, turns sixteen independent requests into sixteen round trips.)
-            double a[QP_RPT];
-            double sq = 0.0;
-#pragma unroll
-            for (int e = 0; e < QP_RPT; ++e) {
-                const int r = tid + QP_THREADS * e, rc = min(r, n - 1);
-                a[e] = A[rc + (long)n * j];
-                double vp[QP_NB];
-#pragma unroll
-                for (int kk = 0; kk < QP_NB; ++kk) vp[kk] = A[rc + (long)n * (j0 + min(kk, kb - 1))];
-#pragma unroll
-                for (int kk = 0; kk < QP_NB; ++kk) a[e] -= ((kk < k && r >= j) ? F[kk * n + j] : 0.0) * vp[kk];
-                sq += (r < n && r >= j) ? a[e] * a[e] : 0.0;
-                if (r == j) red[QP_WAVES] = a[e];
-            }
-            // its squared norm over rows >= j, from scratch, and element j (block reduction in fixed order)
-            sq = wave_sum(sq);
-            if (lane == 0) red[wave] = sq;
             // row j of the earlier reflectors of the panel (needed for the row update below)
             if (tid < QP_NB) aux[QP_NB + tid] = tid < k ? A[j + (long)n * (j0 + tid)] : 0.0;
             __syncthreads();
@@ -321,20 +344,17 @@ __global__ __launch_bounds__(QP_THREADS) void qr_panel_kernel(int n, double *__r
             for (int e = 0; e < QP_RPT; ++e) {
                 const int r = tid + QP_THREADS * e;
                 if (r < n) {
-                    double vr = (r == j) ? 1.0 : 0.0;
-                    if (r >= j) {
-                        double newj = a[e];
-                        if (maxval != 0.0) {
-                            if (r == j) newj = -nu;
-                            else { newj = a[e] / xi; vr = newj; }
-                        }
-                        A[r + (long)n * j] = newj;
+                    double vr = (r == j) ? 1.0 : 0.0, newj = a[e];
+                    if (r >= j && maxval != 0.0) {
+                        if (r == j) newj = -nu;
+                        else { newj = a[e] / xi; vr = newj; }
                     }
+                    if (r >= j || jm != j) A[r + (long)n * j] = newj;  // (rows < j: the R entries the column brought along)
                     v[r] = vr;
                 }
             }
             if (tid == 0) tau[j] = tj;
-            __syncthreads();
+            QP_LDS_BARRIER();  // (v is in LDS; the column-j stores of this step are not read before the next full barrier)
             // ---- F[k][c] = tau A[j:, c]' v for the trailing columns c > j: the ONE pass over the trailing matrix.
             // Every request of a column group goes out before the first product (clamped addresses, no predicates).
             double vq[QMAX];
@@ -366,7 +386,7 @@ __global__ __launch_bounds__(QP_THREADS) void qr_panel_kernel(int n, double *__r
                     }
                 }
             }
-            __syncthreads();
+            QP_LDS_BARRIER();
             // ---- F[:, k] += F[:, 0:k] aux; row j of the trailing matrix (= row j of R); norm down-dating
             for (int c = j + 1 + tid; c < n; c += QP_THREADS) {
                 double f = F[k * n + c], s2 = 0.0;
@@ -381,7 +401,7 @@ __global__ __launch_bounds__(QP_THREADS) void qr_panel_kernel(int n, double *__r
                 const double rjc = ajc - f - s2;  // v[j] = 1
                 A[j + (long)n * c] = rjc;
                 const double t = vn1[c] - rjc * rjc;
-                if (t <= 1e-4 * vn2[c]) todo[1 + atomicAdd(&todo[0], 1)] = c;  // cancellation: take it from scratch
+                if (t <= thr * vn2[c]) todo[1 + atomicAdd(&todo[0], 1)] = c;  // cancellation: take it from scratch
                 else vn1[c] = t;
             }
             __syncthreads();
@@ -1679,7 +1699,7 @@ static hipError_t launch_qr_single(int n, int n_units, double *A, long strideA, 
     }
     // n > 256: the panel (dlaqps-style) kernel, unless it is switched off or its LDS does not fit
     if (n > 256 && n <= 768 && !no_tile && !guard && !src && getenv("DQMC_QR_NOPANEL") == nullptr) {
-        const size_t lds_p = ((size_t)(QP_NB + 4) * n + 2 * QP_NB + QP_WAVES + 2) * sizeof(double) + (size_t)(n + 1) * sizeof(int);
+        const size_t lds_p = ((size_t)(QP_NB + 4) * n + 2 * QP_NB + QP_WAVES + 2) * sizeof(double) + (size_t)(n + 2 + QP_WAVES) * sizeof(int);
         int dev = 0;
         (void)hipGetDevice(&dev);
         static unsigned pmask = 0;
@@ -1688,8 +1708,9 @@ static hipError_t launch_qr_single(int n, int n_units, double *A, long strideA, 
             (void)hipFuncSetAttribute((const void *)qr_panel_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
             pmask |= 1u << dev;
         }
-        if (n <= 576) hipLaunchKernelGGL((qr_panel_kernel<9>), dim3(n_units), dim3(QP_THREADS), lds_p, s, n, A, strideA, tau, pivot);
-        else hipLaunchKernelGGL((qr_panel_kernel<12>), dim3(n_units), dim3(QP_THREADS), lds_p, s, n, A, strideA, tau, pivot);
+        const double thr = getenv("DQMC_QP_THR") ? atof(getenv("DQMC_QP_THR")) : 1e-4;      // recompute threshold (A/B)
+        if (n <= 576) hipLaunchKernelGGL((qr_panel_kernel<9>), dim3(n_units), dim3(QP_THREADS), lds_p, s, n, A, strideA, tau, pivot, thr);
+        else hipLaunchKernelGGL((qr_panel_kernel<12>), dim3(n_units), dim3(QP_THREADS), lds_p, s, n, A, strideA, tau, pivot, thr);
         return hipGetLastError();
     }
     const size_t lds = 2 * 1024 * sizeof(double);
