@@ -323,7 +323,7 @@ static int alloc_qr_workspace(dqmc_handle *h)
     if (h->n > 256) return 0;
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, h->p.device_id));
-    const size_t slots = (size_t)((h->units + 7) / 8) * 8 * 2 * 8;  // units x parity x 8 parts
+    const size_t slots = (size_t)((h->units + 7) / 8) * 8 * QR_COOP_SLOTS_PER_UNIT;
     CHK(dalloc(h, &h->qr_ws.mailbox, slots * QR_COOP_SLOT));
     CHK(dalloc(h, &h->qr_ws.fb, (size_t)2));
     // co-residency: what the occupancy API reports for the kernel on this device (its ~200 VGPRs admit 2 per CU)
@@ -332,6 +332,7 @@ static int alloc_qr_workspace(dqmc_handle *h)
     if (const char *e = getenv("DQMC_QR_TAIL")) h->qr_ws.tail_j0 = atoi(e);  // A/B switches, read per handle
     h->qr_ws.force_sc1 = getenv("DQMC_QR_SC1") != nullptr;
     h->qr_ws.no_coop = getenv("DQMC_QR_NOCOOP") != nullptr;
+    h->qr_ws.rows = getenv("DQMC_QR_ROWS") != nullptr && qr_rows_blocks_per_cu() >= 1;
     if (const char *e = getenv("DQMC_QR_FORCE_TIMEOUT"))
         h->qr_ws.force_timeout = strncmp(e, "step:", 5) == 0 ? 2 + atoi(e + 5) : 1;
     return 0;

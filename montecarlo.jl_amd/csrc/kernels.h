@@ -106,6 +106,7 @@ hipError_t launch_gemm_flush(int n, int n_units, const double *U, const double *
 // Workspace of the cooperative (8 workgroups per matrix) QR: mailbox of n_units x 2 x 8 slots of
 // QR_COOP_SLOT doubles (tagged packets), an error flag (bounded spins), a launch counter.
 constexpr int QR_COOP_SLOT = 528;  // 264 packets of 16 bytes
+constexpr int QR_COOP_SLOTS_PER_UNIT = 24;  // 2 parities x 8 parts (qr_coop_kernel) or 2 x 4 parts x 3 kinds (qr_rows_kernel)
 struct QrCoopWorkspace {
     double *mailbox = nullptr;
     int *errflag = nullptr;
@@ -116,6 +117,7 @@ struct QrCoopWorkspace {
     // A/B and test switches, read from the environment when the workspace is set up (per handle / per primitive call):
     int force_sc1 = 0;      // DQMC_QR_SC1: write-through (agent-scope) packet stores regardless of placement
     int no_coop = 0;        // DQMC_QR_NOCOOP: single-workgroup kernels only
+    int rows = 0;           // DQMC_QR_ROWS: n == 256 two-phase form with the row-split first phase (qr_rows_kernel)
     int force_timeout = 0;  // DQMC_QR_FORCE_TIMEOUT: 1 = every cooperative launch gives up at once;
                             // "step:<j>" -> 2 + j: part 3 of every matrix stops publishing at step j (bounded spins run out)
 };
@@ -129,6 +131,7 @@ hipError_t launch_qr_pivot(int n, int n_units, double *A, long strideA, double *
                            QrCoopWorkspace *ws, double *W, long strideW, const double **factored, hipStream_t s,
                            double *X = nullptr, long strideX = 0);
 int qr_coop_blocks_per_cu();
+int qr_rows_blocks_per_cu();
 
 // After launch_qr_pivot: D = |diag R| (UDT.jl:268-272); V = unit-lower Householder
 // vectors (n x n, explicit zeros/ones); T = D^-1 R:
