@@ -317,6 +317,18 @@ __device__ long long *lu4_stamp_ptr = nullptr;
 #else
 #define LU4_STAMP(idx) do { } while (0)
 #endif
+#ifdef LU4_STAMPS
+#ifndef FL_STAMP_BID
+#define FL_STAMP_BID 1200
+#endif
+#define FL_STAMP(k)                                                                                    \
+    do {                                                                                               \
+        if (bid == FL_STAMP_BID && threadIdx.x == 0 && lu4_stamp_ptr)                                 \
+            lu4_stamp_ptr[480 + (k)] = (long long)__builtin_amdgcn_s_memtime();                       \
+    } while (0)
+#else
+#define FL_STAMP(k) do { } while (0)
+#endif
 // one function per wave role (not inlined into each other: each gets its own register allocation)
 // PRO: the previous chunk (sites site0p ..+63, images imgp_all) has not been applied to G yet: the wave adds its
 // contribution T R0 to its tiles itself (the same two block-triangular solves and K = 64 products as
@@ -978,6 +990,7 @@ __device__ __forceinline__ void flush_lu_body(int bid, int n, int n_units, const
     const int t = m0 + 16 * wave + ci;             // my row of G (contiguous direction)
     const int tq = FULL ? t : min(t, n - 1);
 
+    FL_STAMP(0);
     // the tile of G itself first (the kernel is bound by this read-modify-write)
     d4 acc[NT];
 #pragma unroll
@@ -1011,15 +1024,21 @@ __device__ __forceinline__ void flush_lu_body(int bid, int n, int n_units, const
         const int tl = pass * 64 + (tid >> 2), tp = n0 + tl, s0 = (tid & 3) * 16;
         double *d = Rl + tl * FL_LDR + s0;
         if (FULL) {
-            const double2 *q = reinterpret_cast<const double2 *>(Gin + (long)n * tp + site0 + s0);
+            // (a wave's request covers 2 columns x 512 contiguous bytes = 8 cache lines; one column per 4 lanes with 16
+            // doubles each touched 64 lines per request)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) reinterpret_cast<double2 *>(d)[i] = q[i];
+            for (int i = 0; i < 8; ++i) {
+                const int pc = i * 256 + tid, col = pass * 64 + (pc >> 5), w2 = 2 * (pc & 31);
+                *reinterpret_cast<double2 *>(Rl + col * FL_LDR + w2) =
+                    *reinterpret_cast<const double2 *>(Gin + (long)n * (n0 + col) + site0 + w2);
+            }
         } else {
             for (int i = 0; i < 16; ++i)
                 d[i] = (tp < n && s0 + i < nsites) ? Gin[(long)n * tp + site0 + s0 + i] : 0.0;
         }
     }
     __syncthreads();
+    FL_STAMP(1);
 
     // Z_J = PT_J (C0'_J + sum_{K<J} Uu_KJ' X_K Z_K);  XZ_J = X_J Z_J
     d4 xz[4];
@@ -1053,6 +1072,61 @@ __device__ __forceinline__ void flush_lu_body(int bid, int n, int n_units, const
         for (int q = 0; q < 4; ++q) o = MFMA(img[LU_OFF_Q + J * LU_TILE + q * 64 + lane], a[q], o);
         tt[J] = o;
     }
+    if constexpr (NCP == 0 && FULL && NT == 4) {
+        // run-time pass count (throughput regime: more workgroups than one round): software pipeline over the passes.
+        // While the MFMAs of pass cp run, the G tile and the R0 tile of pass cp + 1 are already on their way (registers);
+        // the R0 tiles alternate between the buffer behind the solves' operands and - the solves being done - the
+        // operands' own place, so a pass needs ONE barrier and LDS stays at 75 KB (two workgroups per CU).
+        double *Rb[2] = {Rl, fsm};
+        FL_STAMP(2);
+        __syncthreads();  // every wave is done with the solves' operands (fsm is reused from pass 1 on)
+        FL_STAMP(3);
+        for (int cp = 0; cp < ncp; ++cp) {
+            const bool more = cp + 1 < ncp;
+            const int n1 = n00 + (more ? cp + 1 : cp) * 64;  // (last pass: harmless re-read of its own tile)
+            d4 nxt[NT];
+            double r0n[16];
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) nxt[jt][r] = Gin[t + (long)n * (n1 + 16 * jt + 4 * r + g)];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int pc = i * 256 + tid;
+                const double2 v = *reinterpret_cast<const double2 *>(Gin + (long)n * (n1 + (pc >> 5)) + site0 + 2 * (pc & 31));
+                r0n[2 * i] = v.x;
+                r0n[2 * i + 1] = v.y;
+            }
+            const double *Rc = Rb[cp & 1];
+#pragma unroll
+            for (int K = 0; K < 4; ++K)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int sk = 16 * K + 4 * q + g;
+#pragma unroll
+                    for (int jt = 0; jt < NT; ++jt) acc[jt] = MFMA(Rc[(16 * jt + ci) * FL_LDR + sk], tt[K][q], acc[jt]);
+                }
+            n0 = n00 + cp * 64;
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Gout[t + (long)n * (n0 + 16 * jt + 4 * r + g)] = acc[jt][r];
+            if (more) {
+                // (the other buffer was last read in pass cp - 1; the barrier of that pass lies between)
+                double *nb = Rb[(cp + 1) & 1];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int pc = i * 256 + tid;
+                    *reinterpret_cast<double2 *>(nb + (pc >> 5) * FL_LDR + 2 * (pc & 31)) = make_double2(r0n[2 * i], r0n[2 * i + 1]);
+                }
+#pragma unroll
+                for (int jt = 0; jt < NT; ++jt) acc[jt] = nxt[jt];
+                __syncthreads();
+            }
+            FL_STAMP(4 + cp);
+        }
+        return;
+    }
     for (int cp = 0; cp < ncp; ++cp) {
         if (cp > 0) {  // next 16 NT columns: G tile and R0 tile again (the solves are done)
             n0 = n00 + cp * 16 * NT;
@@ -1069,9 +1143,12 @@ __device__ __forceinline__ void flush_lu_body(int bid, int n, int n_units, const
                 const int tl = pass * 64 + (tid >> 2), tp = n0 + tl, s0 = (tid & 3) * 16;
                 double *d = Rl + tl * FL_LDR + s0;
                 if (FULL) {
-                    const double2 *q = reinterpret_cast<const double2 *>(Gin + (long)n * tp + site0 + s0);
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) reinterpret_cast<double2 *>(d)[i] = q[i];
+                    for (int i = 0; i < 8; ++i) {
+                        const int pc = i * 256 + tid, col = pass * 64 + (pc >> 5), w2 = 2 * (pc & 31);
+                        *reinterpret_cast<double2 *>(Rl + col * FL_LDR + w2) =
+                            *reinterpret_cast<const double2 *>(Gin + (long)n * (n0 + col) + site0 + w2);
+                    }
                 } else {
                     for (int i = 0; i < 16; ++i)
                         d[i] = (tp < n && s0 + i < nsites) ? Gin[(long)n * tp + site0 + s0 + i] : 0.0;
@@ -1381,7 +1458,14 @@ hipError_t launch_sweep_flush_lu(int n, int n_units, const double *Gin, double *
         n_cus[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
     }
     const bool ncp2 = ncp2_env || (dev >= 0 && dev < 32 && groups * 8 * tm * tn > n_cus[dev]);
-    if (ncp2 && wide && full && n % 256 == 0) {
+    // (n % 256 == 0 used to take 128-column passes here: 109 KB of LDS, one workgroup per CU, 230 us per launch of 512 units;
+    // 64-column passes - 75 KB, two workgroups per CU - 190 us, software-pipelined 187.  A third workgroup per CU (R0 tile
+    // aliased onto the solves' operands, 41 KB): 193 us; a late start of every other workgroup: slower by the delay.
+    // In-kernel stamps (tools/fl_stamps.py): 38 k cycles until the operands of a workgroup are there, 8 - 10 k of solves,
+    // 12 - 16 k per pass of 4 k cycles of MFMA - all resident workgroups fetch at ~17 B/cycle/CU, which is what the part
+    // delivers to every CU at once; PMC: HBM traffic = algorithmic (profiles/r03_pmc_flush_512units.txt))
+    const bool nt8_env = getenv("DQMC_FLUSH_NT8") != nullptr;  // the former form, for A/B
+    if (ncp2 && wide && full && n % 256 == 0 && (nt8_env || ncp2_env)) {
         static unsigned m2 = 0;
         if (!(m2 & (1u << dev))) {
             (void)hipFuncSetAttribute((const void *)sweep_flush_lu_kernel<true, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1394,15 +1478,17 @@ hipError_t launch_sweep_flush_lu(int n, int n_units, const double *Gin, double *
     }
     // n not a multiple of 128 (64-column tiles, e.g. n = 576: 9 x 9 tiles per unit, every row tile's solves done 9
     // times over) and more than one round of workgroups: ONE workgroup per 64-row tile, all column tiles in passes
-    if (ncp2 && !wide && full && tn > 1) {
+    if (ncp2 && full && (n + 63) / 64 > 1) {
+        const int tn4 = (n + 63) / 64;
+        const size_t lds4 = ((size_t)LU_STRIDE + 64 * FL_LDR) * sizeof(double);
         static unsigned m0 = 0;
         if (!(m0 & (1u << dev))) {
             (void)hipFuncSetAttribute((const void *)sweep_flush_lu_kernel<true, 4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)(((size_t)LU_STRIDE + 128 * FL_LDR) * sizeof(double)));
             m0 |= 1u << dev;
         }
-        hipExtLaunchKernelGGL((sweep_flush_lu_kernel<true, 4, 0>), dim3(groups * 8 * tm), dim3(256), lds, s, start, stop, 0, n,
-                              n_units, Gin, Gout, strideG, site0, nsites, img, tm, 1, tn);
+        hipExtLaunchKernelGGL((sweep_flush_lu_kernel<true, 4, 0>), dim3(groups * 8 * tm), dim3(256), lds4, s, start, stop, 0, n,
+                              n_units, Gin, Gout, strideG, site0, nsites, img, tm, 1, tn4);
         return hipGetLastError();
     }
     if (wide) { if (full) FL_LAUNCH(true, 8); else FL_LAUNCH(false, 8); }
