@@ -2031,7 +2031,8 @@ int dqmc_mfma_f64_peak(int32_t device_id, int32_t iters, double *tflops)
     SCHK(dalloc(h, &sink, 16));
     hipDeviceProp_t prop;
     SHIP(hipGetDeviceProperties(&prop, device_id));
-    const int blocks = prop.multiProcessorCount * 2;  // 8 waves per CU = 2 per SIMD
+    // 8 waves per CU = 2 per SIMD, the occupancy of the GEMM launches at 32 units (DQMC_PROBE_WG_PER_CU: other occupancies)
+    const int blocks = prop.multiProcessorCount * (getenv("DQMC_PROBE_WG_PER_CU") ? atoi(getenv("DQMC_PROBE_WG_PER_CU")) : 2);
     hipEvent_t a, b;
     SHIP(hipEventCreate(&a)); SHIP(hipEventCreate(&b));
     SHIP(launch_mfma_peak(iters / 8 + 1, blocks, sink, h->stream));  // warm up
