@@ -50,6 +50,17 @@ __device__ __forceinline__ double readlane_d(double v, int lane)
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+// Pointers into device memory, typed as such.  Inside a __noinline__ device function, or when a pointer reaches the kernel
+// inside a by-value struct, the compiler only knows a generic pointer: every access becomes a FLAT operation, which counts
+// in vmcnt AND lgkmcnt (each wait for an LDS read then also waits for the global requests in flight) and may alias LDS
+// (a load followed by an LDS store is then waited for on the spot: the staging loops of the flush workgroups inside the
+// fused launch were 27 round trips one after the other).  With the address space in the type they are global_load /
+// global_store again.
+#define DQMC_GLOBAL __attribute__((address_space(1)))
+typedef const DQMC_GLOBAL double *gcdp;
+typedef DQMC_GLOBAL double *gdp;
+typedef double d2v __attribute__((ext_vector_type(2)));  // (HIP's double2 is a class: no assignment from address space 1)
+typedef const DQMC_GLOBAL d2v *gcd2p;
 
 // Accumulator layout of v_mfma_f64_16x16x4_f64: register r of lane l = (g = l >> 4, ci = l & 15) holds element
 // [4 r + g][ci] of a 16 x 16 tile; the A operand is A[i = ci][k = g], the B operand B[k = g][j = ci].
@@ -198,7 +209,7 @@ __global__ __launch_bounds__(64) void sweep_lu_kernel(int n, const double *__res
         // block row I0 is final: register images for the flush kernel
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            double *__restrict__ img = img_all + (long)(w * NB + b) * LU_STRIDE;
+            const gdp img = (gdp)(img_all + (long)(w * NB + b) * LU_STRIDE);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 // element [4 r + g][ci] goes to A-operand position (i = 4 r + g, k = ci) of the transposed tile
@@ -216,7 +227,7 @@ __global__ __launch_bounds__(64) void sweep_lu_kernel(int n, const double *__res
     if (!FULL) {  // blocks past the end of a short chunk: identity triangles
         for (int I0 = (nsites + 15) / 16; I0 < 4; ++I0)
             for (int b = 0; b < NB; ++b) {
-                double *__restrict__ img = img_all + (long)(w * NB + b) * LU_STRIDE;
+                const gdp img = (gdp)(img_all + (long)(w * NB + b) * LU_STRIDE);
                 for (int r = 0; r < 4; ++r) {
                     const double idv = (4 * r + g == ci) ? 1.0 : 0.0;
                     for (int J = I0 + 1; J < 4; ++J) {
@@ -348,7 +359,7 @@ __device__ __noinline__ void lu4_wave(int n, const double *__restrict__ Gall, lo
     d4 S[NB][J + 1], ST[NB][J + 1];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-        const double *__restrict__ G = Gall + (long)(w * NB + b) * strideG + (long)site0 * n + site0;
+        const gcdp G = (gcdp)(Gall + (long)(w * NB + b) * strideG + (long)site0 * n + site0);
 #pragma unroll
         for (int I = 0; I <= J; ++I)
 #pragma unroll
@@ -386,8 +397,8 @@ __device__ __noinline__ void lu4_wave(int n, const double *__restrict__ Gall, lo
         const int tid = threadIdx.x;
 #pragma unroll 1
         for (int b = 0; b < NB; ++b) {
-            const double *__restrict__ Gin = Gall + (long)(w * NB + b) * strideG;
-            const double *__restrict__ imgp = imgp_all + (long)(w * NB + b) * LU_STRIDE;
+            const gcdp Gin = (gcdp)(Gall + (long)(w * NB + b) * strideG);
+            const gcdp imgp = (gcdp)(imgp_all + (long)(w * NB + b) * LU_STRIDE);
             const int t = site0 + 16 * J + ci;
             d4 az[4];
 #pragma unroll
@@ -395,10 +406,10 @@ __device__ __noinline__ void lu4_wave(int n, const double *__restrict__ Gall, lo
 #pragma unroll
                 for (int r = 0; r < 4; ++r) az[Jb][r] = Gin[t + (long)n * (site0p + 16 * Jb + 4 * r + g)];
             // R0 block: thread -> column t' = tid / 4 of this chunk, 16 consecutive sites of the previous one
-            double2 r0v[8];
+            d2v r0v[8];
             {
                 const int tl = tid >> 2, s0 = (tid & 3) * 16;
-                const double2 *q = reinterpret_cast<const double2 *>(Gin + (long)n * (site0 + tl) + site0p + s0);
+                const gcd2p q = reinterpret_cast<gcd2p>(Gin + (long)n * (site0 + tl) + site0p + s0);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) r0v[i] = q[i];
             }
@@ -411,9 +422,9 @@ __device__ __noinline__ void lu4_wave(int n, const double *__restrict__ Gall, lo
             double opU[STAGE ? 1 : 6][4], opL[STAGE ? 1 : 6][4], opP[STAGE ? 1 : 4][4], opQ[STAGE ? 1 : 4][4], xr[4][4];
             if (STAGE) {
                 constexpr int NI = (LU_STRIDE / 2 + 255) / 256;
-                const double2 *src = reinterpret_cast<const double2 *>(imgp);
-                double2 *dst = reinterpret_cast<double2 *>(imgl);
-                double2 iv[NI];
+                const gcd2p src = reinterpret_cast<gcd2p>(imgp);
+                d2v *dst = reinterpret_cast<d2v *>(imgl);
+                d2v iv[NI];
 #pragma unroll
                 for (int i = 0; i < NI; ++i) iv[i] = src[min(tid + 256 * i, LU_STRIDE / 2 - 1)];
 #pragma unroll
@@ -437,7 +448,7 @@ __device__ __noinline__ void lu4_wave(int n, const double *__restrict__ Gall, lo
             }
             {   // (all loads of the prologue are in flight by now: one round trip)
                 const int tl = tid >> 2, s0 = (tid & 3) * 16;
-                double2 *d = reinterpret_cast<double2 *>(Rl + tl * 66 + s0);
+                d2v *d = reinterpret_cast<d2v *>(Rl + tl * 66 + s0);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) d[i] = r0v[i];
             }
@@ -807,7 +818,7 @@ __device__ __noinline__ void lu4_wave(int n, const double *__restrict__ Gall, lo
         LU4_STAMP(320 + 8 * J + 2 + I0);
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            double *__restrict__ img = img_all + (long)(w * NB + b) * LU_STRIDE;
+            const gdp img = (gdp)(img_all + (long)(w * NB + b) * LU_STRIDE);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int tpos = (ci >> 2) * 64 + 16 * (ci & 3) + 4 * r + g;
@@ -877,7 +888,7 @@ __device__ __forceinline__ void lu4_block(int w, int n, const double *__restrict
         const int I0 = wv, g = lane >> 4, ci = lane & 15;
         if (I0 >= nblk)
             for (int b = 0; b < NB; ++b) {
-                double *__restrict__ img = img_all + (long)(w * NB + b) * LU_STRIDE;
+                const gdp img = (gdp)(img_all + (long)(w * NB + b) * LU_STRIDE);
                 for (int r = 0; r < 4; ++r) {
                     const double idv = (4 * r + g == ci) ? 1.0 : 0.0;
                     for (int Jc = I0 + 1; Jc < 4; ++Jc) {
@@ -984,8 +995,8 @@ __device__ __forceinline__ void flush_lu_body(int bid, int n, int n_units, const
     const int tile = seq % T;
     const int m0 = (tile % tiles_m) * 64, n00 = (tile / tiles_m) * (16 * NT * ncp);
     int n0 = n00;
-    const double *__restrict__ Gin = Gin_all + (long)unit * strideG;
-    double *__restrict__ Gout = Gout_all + (long)unit * strideG;
+    const gcdp Gin = (gcdp)(Gin_all + (long)unit * strideG);
+    const gdp Gout = (gdp)(Gout_all + (long)unit * strideG);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, ci = lane & 15;
     const int t = m0 + 16 * wave + ci;             // my row of G (contiguous direction)
     const int tq = FULL ? t : min(t, n - 1);
@@ -1014,8 +1025,8 @@ __device__ __forceinline__ void flush_lu_body(int bid, int n, int n_units, const
         }
     // static operands of the triangles and x
     {
-        const double2 *src = reinterpret_cast<const double2 *>(img_all + (long)unit * LU_STRIDE);
-        double2 *dst = reinterpret_cast<double2 *>(img);
+        const gcd2p src = reinterpret_cast<gcd2p>((gcdp)(img_all + (long)unit * LU_STRIDE));
+        d2v *dst = reinterpret_cast<d2v *>(img);
         for (int i = tid; i < LU_STRIDE / 2; i += 256) dst[i] = src[i];
     }
     // R0 tile: thread -> column t' = pass * 64 + tid / 4, 16 consecutive s
@@ -1029,8 +1040,8 @@ __device__ __forceinline__ void flush_lu_body(int bid, int n, int n_units, const
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int pc = i * 256 + tid, col = pass * 64 + (pc >> 5), w2 = 2 * (pc & 31);
-                *reinterpret_cast<double2 *>(Rl + col * FL_LDR + w2) =
-                    *reinterpret_cast<const double2 *>(Gin + (long)n * (n0 + col) + site0 + w2);
+                *reinterpret_cast<d2v *>(Rl + col * FL_LDR + w2) =
+                    *reinterpret_cast<gcd2p>(Gin + (long)n * (n0 + col) + site0 + w2);
             }
         } else {
             for (int i = 0; i < 16; ++i)
@@ -1077,7 +1088,8 @@ __device__ __forceinline__ void flush_lu_body(int bid, int n, int n_units, const
         // While the MFMAs of pass cp run, the G tile and the R0 tile of pass cp + 1 are already on their way (registers);
         // the R0 tiles alternate between the buffer behind the solves' operands and - the solves being done - the
         // operands' own place, so a pass needs ONE barrier and LDS stays at 75 KB (two workgroups per CU).
-        double *Rb[2] = {Rl, fsm};
+        const int rb_off[2] = {(int)(Rl - fsm), 0};  // offsets, not pointers: a run-time choice between two pointers loses
+                                                     // the LDS address space (every operand read became a flat load)
         FL_STAMP(2);
         __syncthreads();  // every wave is done with the solves' operands (fsm is reused from pass 1 on)
         FL_STAMP(3);
@@ -1093,11 +1105,11 @@ __device__ __forceinline__ void flush_lu_body(int bid, int n, int n_units, const
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int pc = i * 256 + tid;
-                const double2 v = *reinterpret_cast<const double2 *>(Gin + (long)n * (n1 + (pc >> 5)) + site0 + 2 * (pc & 31));
+                const d2v v = *reinterpret_cast<gcd2p>(Gin + (long)n * (n1 + (pc >> 5)) + site0 + 2 * (pc & 31));
                 r0n[2 * i] = v.x;
                 r0n[2 * i + 1] = v.y;
             }
-            const double *Rc = Rb[cp & 1];
+            const double *Rc = fsm + rb_off[cp & 1];
 #pragma unroll
             for (int K = 0; K < 4; ++K)
 #pragma unroll
@@ -1113,7 +1125,7 @@ __device__ __forceinline__ void flush_lu_body(int bid, int n, int n_units, const
                 for (int r = 0; r < 4; ++r) Gout[t + (long)n * (n0 + 16 * jt + 4 * r + g)] = acc[jt][r];
             if (more) {
                 // (the other buffer was last read in pass cp - 1; the barrier of that pass lies between)
-                double *nb = Rb[(cp + 1) & 1];
+                double *nb = fsm + rb_off[(cp + 1) & 1];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int pc = i * 256 + tid;
@@ -1146,8 +1158,8 @@ __device__ __forceinline__ void flush_lu_body(int bid, int n, int n_units, const
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const int pc = i * 256 + tid, col = pass * 64 + (pc >> 5), w2 = 2 * (pc & 31);
-                        *reinterpret_cast<double2 *>(Rl + col * FL_LDR + w2) =
-                            *reinterpret_cast<const double2 *>(Gin + (long)n * (n0 + col) + site0 + w2);
+                        *reinterpret_cast<d2v *>(Rl + col * FL_LDR + w2) =
+                            *reinterpret_cast<gcd2p>(Gin + (long)n * (n0 + col) + site0 + w2);
                     }
                 } else {
                     for (int i = 0; i < 16; ++i)

@@ -14,7 +14,21 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 // registers), and leave it in LDS as a register image; after ONE barrier every wave subtracts T[J, L]' X_J' from its
 // later tiles (four MFMAs each, B operand = that image, A operand = the T row panel staged in LDS one step ahead).
 // The owners of block J + 1 update that tile first, so consecutive steps overlap.  Panel parameters as above.
+#ifdef TR_STAMPS  // diagnostic build only (tools/tr_stamps.py): cycle stamps of workgroup 0
+__device__ long long *tr_stamp_ptr = nullptr;
+#define TR_STAMP(idx)                                                                                        \
+    do {                                                                                                     \
+        if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && tr_stamp_ptr)                                      \
+            tr_stamp_ptr[(threadIdx.x >> 6) * 64 + (idx)] = (long long)__builtin_amdgcn_s_memtime();         \
+    } while (0)
+#else
+#define TR_STAMP(idx) do { } while (0)
+#endif
 constexpr int TR_TS = 18;  // LDS stride of a column of the T row panel (16 rows + pad)
+// FULLB: n == 256 columns (16 blocks) and whole 32-row slabs - no bounds anywhere, so a step is straight-line code (the
+// scheduler can request a step's LDS operands together and issue its MFMAs back to back; with run-time bounds every tile
+// sat behind a scalar branch and every pair of MFMAs waited for the LDS read issued just before it)
+template <bool FULLB>
 __global__ __launch_bounds__(256) void trsm_rl_kernel(int nr, int n, int c0, int ld, int nblk_all,
                                                      const double *__restrict__ Aall, long sA,
                                                      const double *__restrict__ Tall, long sT,
@@ -26,7 +40,7 @@ __global__ __launch_bounds__(256) void trsm_rl_kernel(int nr, int n, int c0, int
     extern __shared__ __attribute__((aligned(16))) double trl_sm[];
     double (*Tl)[256 * TR_TS] = reinterpret_cast<double (*)[256 * TR_TS]>(trl_sm);
     double (*Xi)[2][4 * 64] = reinterpret_cast<double (*)[2][4 * 64]>(trl_sm + 3 * 256 * TR_TS);  // [J & 1][rt]: image of X_J'
-    double (*Wi)[4 * 64] = reinterpret_cast<double (*)[4 * 64]>(trl_sm + 3 * 256 * TR_TS + 2 * 2 * 256);  // [J & 1]: W_J'
+    double (*Wl)[4 * 64] = reinterpret_cast<double (*)[4 * 64]>(trl_sm + 3 * 256 * TR_TS + 2 * 2 * 256);  // [J]: W_J' (all 16)
     // XCD-aware map (as in gemm_f64.hip): the slabs of one unit share an XCD, so its T is fetched into one L2 only
     const int bid = blockIdx.x, xcd = bid & 7, seq = bid >> 3;
     const int unit = (seq / slabs) * 8 + xcd, row0 = (seq % slabs) * 32;
@@ -37,116 +51,192 @@ __global__ __launch_bounds__(256) void trsm_rl_kernel(int nr, int n, int c0, int
     double *__restrict__ O = Oall + (long)unit * sO;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, ci = lane & 15;
     const int rt = w & 1, par = w >> 1;
-    const int nblk = (n + 15) >> 4;
+    const int nblk = FULLB ? 16 : (n + 15) >> 4;
     const double *__restrict__ Wu = Wall + ((long)unit * nblk_all + (c0 >> 4)) * 256;
     const int row = row0 + 16 * rt + ci;
     const int rowc = min(row, nr - 1);
 
+    TR_STAMP(0);
     // my tiles: block L = 2 t + par; element [4 r + g][ci] = X[row][c0 + 16 L + 4 r + g]
+    // All 32 pivot entries first, then the 32 gathered columns, and the bounds applied as a 0/1 FACTOR: with
+    // `ok ? v : 0.0` the compiler sinks every load into an exec-mask branch of its own and waits for it at the merge
+    // (s_waitcnt vmcnt(0)) - 32 trips to the L2 one after the other, 37 k cycles of a 120 k cycle kernel (stamps,
+    // tools/tr_stamps.py).  Addresses are clamped, so what is multiplied by 0 is a finite matrix element.
     d4_t x[8];
+    int pjv[8][4];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int cc = min(16 * (2 * t + par) + 4 * r + g, n - 1);
+            pjv[t][r] = piv ? piv[c0 + cc] : c0 + cc;
+        }
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
         const int L = 2 * t + par;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int col = 16 * L + 4 * r + g;
-            const int cc = min(col, n - 1);
-            const int pj = piv ? piv[c0 + cc] : c0 + cc;
-            const double v = A[rowc + (long)ld * pj];
-            x[t][r] = (L < nblk && col < n && row < nr) ? v : 0.0;
+            const double v = A[(unsigned)(rowc + ld * pjv[t][r])];
+            x[t][r] = v * ((L < nblk && col < n && row < nr) ? 1.0 : 0.0);
         }
     }
-    // Staging of step J: the T row panel (rows 16 J .. +15 of the block, later columns) and W_J'.  Requested into
-    // registers one step before it is written to LDS (two steps before it is read), so no step waits for L2:
-    // thread -> row k = tid & 15 of the columns c = (tid >> 4) + 16 i: one instruction covers 4 columns x 128 bytes.
-    double pv[16], pw = 0.0;
-    auto request = [&](int J) {
+#ifdef TR_STAMPS
+    TR_STAMP(40);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TR_STAMP(41);
+#endif
+    // Staging of step J: the T row panel (rows 16 J .. +15 of the block, later columns).  thread -> row k = tid & 15 of
+    // the columns c = (tid >> 4) + 16 i: one instruction covers 4 columns x 128 bytes.  Register ring of THREE panels
+    // (round 3: requested four steps before they are read, in LDS two steps before); the sixteen W_J' are staged in LDS
+    // once, before the first step.
+    constexpr int TR_RING = 3;
+    double pv[TR_RING][16];
+    auto request = [&](auto Jc) {
+        constexpr int J = decltype(Jc)::value, S = J % TR_RING;
         if (J >= nblk) return;
-        const int k = min(16 * J + (tid & 15), n - 1);
+        const int k = FULLB ? 16 * J + (tid & 15) : min(16 * J + (tid & 15), n - 1);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int c = min((tid >> 4) + 16 * i, n - 1);
-            pv[i] = T[(long)ld * c + k];
+        for (int i = (FULLB ? J + 1 : 0); i < 16; ++i) {  // (FULLB: only the columns of later blocks are ever read)
+            const int c = FULLB ? (tid >> 4) + 16 * i : min((tid >> 4) + 16 * i, n - 1);
+            pv[S][i] = T[(unsigned)(ld * c + k)];  // (32-bit offsets from the unit's scalar base: one VALU op per address)
         }
-        // W_J (16 x 16, column-major W[k + 16 c]) as the A operand of X_J' = W_J' R_J':  A(i = ci, k = 4 q + g) = W[4 q + g][ci]
-        const int q = tid >> 6, l = tid & 63;
-        pw = Wu[(long)J * 256 + (4 * q + (l >> 4)) + 16 * (l & 15)];
     };
-    auto deposit = [&](int J) {
+    auto deposit = [&](auto Jc) {
+        constexpr int J = decltype(Jc)::value, S = J % TR_RING;
         if (J >= nblk) return;
         double *tl = Tl[J % 3];
         const int k = tid & 15;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = (FULLB ? J + 1 : 0); i < 16; ++i) {
             const int c = (tid >> 4) + 16 * i;
-            const bool live = c < n && c >= 16 * (J + 1) && 16 * J + k < n;
-            tl[c * TR_TS + k] = live ? pv[i] : 0.0;
+            const bool live = FULLB || (c < n && c >= 16 * (J + 1) && 16 * J + k < n);
+            tl[c * TR_TS + k] = live ? pv[S][i] : 0.0;
         }
-        Wi[J & 1][tid] = pw;
     };
-    request(0);
-    deposit(0);
-    request(1);
+    // owner of block J (wave-uniform): X_J' = W_J' R_J' from its own registers -> LDS image + output
+    auto finish = [&](auto Jc) {
+        constexpr int J = decltype(Jc)::value, t_own = J >> 1;
+        d4_t o = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o = __builtin_amdgcn_mfma_f64_16x16x4f64(Wl[J][q * 64 + lane], x[t_own][q], o, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            Xi[J & 1][rt][r * 64 + lane] = o[r];
+            const int col = 16 * J + 4 * r + g;
+            if (FULLB || (row < nr && col < n)) O[(unsigned)(row + ld * (c0 + col))] = o[r];
+        }
+    };
+#define TRL_IC(K) std::integral_constant<int, (K)>{}
+    request(TRL_IC(0));
+    request(TRL_IC(1));
+    request(TRL_IC(2));
+    {   // all W_J (16 x 16, column-major W[k + 16 c]) as A operands of X_J' = W_J' R_J':  A(i = ci, k = 4 q + g) = W[4 q + g][ci]
+        const int q = tid >> 6, l = tid & 63, src = (4 * q + (l >> 4)) + 16 * (l & 15);
+        double wv[16];
+#pragma unroll
+        for (int J = 0; J < 16; ++J) wv[J] = Wu[(unsigned)((FULLB ? J : min(J, nblk - 1)) * 256 + src)];
+#pragma unroll
+        for (int J = 0; J < 16; ++J) Wl[J][tid] = wv[J];
+    }
+#ifdef TR_STAMPS
+    TR_STAMP(42);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TR_STAMP(43);
+#endif
+    deposit(TRL_IC(0));
+    TR_STAMP(44);
     __syncthreads();
-    // one step; J is a compile-time constant (tile indices must be static: the tiles live in registers)
+    TR_STAMP(1);
+    if (par == 0) finish(TRL_IC(0));
+    deposit(TRL_IC(1));
+    request(TRL_IC(3));
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // One step (J is a compile-time constant: the tiles live in registers).  Look-ahead (round 3): the owner of block
+    // J + 1 brings that tile up to date FIRST and finishes it right away - image in LDS, output on its way - and only
+    // then updates its other tiles, so the next step's X is ready when everybody arrives at the barrier.  (Before, a
+    // wave issued all its updates - up to 32 MFMAs - before the four MFMAs the next step was waiting for: 4 - 6 k cycles
+    // per step against ~2.3 k of MFMA issue.)
     auto step = [&](auto Jc) {
         constexpr int J = decltype(Jc)::value;
-        if (J >= nblk) return;
-        constexpr int t_own = J >> 1;
-        if ((J & 1) == par) {  // owner of block J (wave-uniform): finish it
-            d4_t o = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) o = __builtin_amdgcn_mfma_f64_16x16x4f64(Wi[J & 1][q * 64 + lane], x[t_own][q], o, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                Xi[J & 1][rt][r * 64 + lane] = o[r];
-                const int col = 16 * J + 4 * r + g;
-                if (row < nr && col < n) O[row + (long)ld * (c0 + col)] = o[r];
-            }
-        }
-        deposit(J + 1);
-        request(J + 2);
-        // X_J' and the staging of step J + 1 are visible; buffers of step J - 1 are free.  LDS-only barrier:
-        // __syncthreads() would also drain the global loads just requested for step J + 2
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (!FULLB && J >= nblk) return;
         const double *xi = Xi[J & 1][rt];
         const double *tl = Tl[J % 3];
-        const double b0 = xi[lane], b1 = xi[64 + lane], b2 = xi[128 + lane], b3 = xi[192 + lane];
+        // (-X_J' once per step: negating the T operand cost one VALU op per MFMA)
+        const double b0 = -xi[lane], b1 = -xi[64 + lane], b2 = -xi[128 + lane], b3 = -xi[192 + lane];
+        // (the four MFMAs of a tile depend on each other: tiles are interleaved, k-quad by k-quad, so that consecutive
+        // MFMAs are independent - issued tile by tile a wave spent ~190 cycles per MFMA instead of 64)
+        auto body = [&](auto pc) {
+            constexpr int PAR = decltype(pc)::value;
+            constexpr bool own_next = J + 1 < 16 && ((J + 1) & 1) == PAR;
+            constexpr int t_next = (J + 1) >> 1;  // tile index of block J + 1 in its owner
+            if constexpr (own_next) {
+                if (FULLB || J + 1 < nblk) {  // look-ahead: block J + 1 first, and finished right away
+                    const double *ta = tl + (16 * (J + 1) + ci) * TR_TS + g;
+                    x[t_next] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[0], b0, x[t_next], 0, 0, 0);
+                    x[t_next] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[4], b1, x[t_next], 0, 0, 0);
+                    x[t_next] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[8], b2, x[t_next], 0, 0, 0);
+                    x[t_next] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[12], b3, x[t_next], 0, 0, 0);
+                    finish(TRL_IC(J + 1 < 16 ? J + 1 : 15));
+                }
+            }
+            constexpr int t_first = own_next ? t_next + 1 : (J + 2 - PAR) / 2;  // first tile with 2 t + PAR > J (+ not t_next)
+            const double bq[4] = {b0, b1, b2, b3};
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const int L = 2 * t + par;
-            if (L <= J) continue;          // compile time
-            if (L >= nblk) continue;       // wave-uniform
-            const double *ta = tl + (16 * L + ci) * TR_TS + g;  // A(i = ci, k = 4 q + g) = T[16 J + 4 q + g][16 L + ci]
-            x[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ta[0], b0, x[t], 0, 0, 0);
-            x[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ta[4], b1, x[t], 0, 0, 0);
-            x[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ta[8], b2, x[t], 0, 0, 0);
-            x[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ta[12], b3, x[t], 0, 0, 0);
-        }
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int t = t_first; t < 8; ++t) {
+                    if (!FULLB && 2 * t + PAR >= nblk) continue;  // wave-uniform
+                    const double *ta = tl + (16 * (2 * t + PAR) + ci) * TR_TS + g;  // A(i = ci, k = 4 q + g) = T[16 J + 4 q + g][16 L + ci]
+                    x[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[4 * q], bq[q], x[t], 0, 0, 0);
+                }
+        };
+        if (par == 0) body(TRL_IC(0));
+        else body(TRL_IC(1));
+        deposit(TRL_IC(J + 2));
+        request(TRL_IC(J + 4));
+        // X_{J+1}' and the panel of step J + 2 are visible; buffers of step J are free.  LDS-only barrier:
+        // __syncthreads() would also drain the global loads requested for the coming steps
+        TR_STAMP(2 + 2 * J);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        TR_STAMP(3 + 2 * J);
     };
 #define TRL_STEP(K) step(std::integral_constant<int, K>{})
     TRL_STEP(0); TRL_STEP(1); TRL_STEP(2); TRL_STEP(3); TRL_STEP(4); TRL_STEP(5); TRL_STEP(6); TRL_STEP(7);
     TRL_STEP(8); TRL_STEP(9); TRL_STEP(10); TRL_STEP(11); TRL_STEP(12); TRL_STEP(13); TRL_STEP(14); TRL_STEP(15);
 #undef TRL_STEP
+#undef TRL_IC
+    TR_STAMP(34);
 }
+#ifdef TR_STAMPS
+extern "C" int dqmc_debug_tr_stamps(void *devptr)
+{
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(tr_stamp_ptr), &devptr, sizeof(void *));
+}
+#endif
 
 hipError_t launch_trsm_rl(int nr, int nc, int c0, int ld, int nblk_all, int n_units, const double *A, long sA,
                           const double *T, long sT, const int *pivot, double *Out, long sO, const double *winv,
                           hipStream_t s)
 {
     if (nc > 256 || nc < 1) return hipErrorInvalidValue;
-    const size_t lds_r = (3 * 256 * TR_TS + 2 * 2 * 256 + 2 * 256) * sizeof(double);
+    const size_t lds_r = (3 * 256 * TR_TS + 2 * 2 * 256 + 16 * 256) * sizeof(double);  // 148 KB
     int dev = 0;
     (void)hipGetDevice(&dev);
     static unsigned attr_mask = 0;  // per device
     if (!(attr_mask & (1u << dev))) {
-        (void)hipFuncSetAttribute((const void *)trsm_rl_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r);
+        (void)hipFuncSetAttribute((const void *)trsm_rl_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r);
+        (void)hipFuncSetAttribute((const void *)trsm_rl_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r);
         attr_mask |= 1u << dev;
     }
     const int slabs = (nr + 31) / 32;
     const int groups = (n_units + 7) / 8;
-    hipLaunchKernelGGL(trsm_rl_kernel, dim3(groups * 8 * slabs), dim3(256), lds_r, s, nr, nc, c0, ld, nblk_all, A, sA, T, sT,
-                       pivot, Out, sO, slabs, winv, n_units);
+    if (nc == 256 && nr % 32 == 0 && !getenv("DQMC_TRSM_BOUNDS"))
+        hipLaunchKernelGGL(trsm_rl_kernel<true>, dim3(groups * 8 * slabs), dim3(256), lds_r, s, nr, nc, c0, ld, nblk_all, A, sA, T,
+                           sT, pivot, Out, sO, slabs, winv, n_units);
+    else
+        hipLaunchKernelGGL(trsm_rl_kernel<false>, dim3(groups * 8 * slabs), dim3(256), lds_r, s, nr, nc, c0, ld, nblk_all, A, sA,
+                           T, sT, pivot, Out, sO, slabs, winv, n_units);
     return hipGetLastError();
 }
 
