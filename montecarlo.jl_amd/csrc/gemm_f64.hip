@@ -83,7 +83,8 @@ __device__ __forceinline__ void tile_store(double (*Xs)[LS], int tid, const doub
 // an L2 round trip into every k-step.
 #define GEMM_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
-// KSM: the k-scaling mode as a compile-time constant (0 none, 2 conf-derived; -1 = read it from the arguments): the
+// KSM: the k-scaling mode as a compile-time constant (0 none, 2 conf-derived, 1/3/4/5 the array modes; -1 = read it from the
+// arguments: partial tiles only): the
 // per-k-tile mode dispatch, its register copies and its divisions leave the loop for the two common cases
 template <bool TA, bool TB, bool FULL, int KSM>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, int tiles_m, int tiles_n, int gemm_stagger)
@@ -146,6 +147,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, int tiles_m, int 
 #pragma unroll
             for (int i = 0; i < NKS; ++i) {
                 const int kk = min(kb + i, g.K - 1);  // clamped: rows past K hold zeros in the tile anyway
+                // (the mode is a compile-time constant in the full-tile launches: with the run-time choice between the two
+                // sources, and between the four array modes when the factor is applied, the requests of a k-tile sat in
+                // branches and were waited for on the spot)
                 if (ksmode == 2) qc[i] = g.kscale.conf[(long)kw * g.kscale.conf_stride + kk];
                 else qd[i] = g.kscale.d[(long)unit * g.kscale.stride + kk];
             }
@@ -277,6 +281,10 @@ hipError_t launch_gemm(const GemmArgs &g, hipStream_t s, hipEvent_t start, hipEv
         if (!full) GEMM_LAUNCH4(TA, TB, false, -1);                                \
         else if (g.kscale.mode == 0) GEMM_LAUNCH4(TA, TB, true, 0);                \
         else if (g.kscale.mode == 2) GEMM_LAUNCH4(TA, TB, true, 2);                \
+        else if (g.kscale.mode == 1) GEMM_LAUNCH4(TA, TB, true, 1);                \
+        else if (g.kscale.mode == 3) GEMM_LAUNCH4(TA, TB, true, 3);                \
+        else if (g.kscale.mode == 4) GEMM_LAUNCH4(TA, TB, true, 4);                \
+        else if (g.kscale.mode == 5) GEMM_LAUNCH4(TA, TB, true, 5);                \
         else GEMM_LAUNCH4(TA, TB, true, -1);                                       \
     } while (0)
     if (g.transA) {

@@ -481,6 +481,11 @@ __global__ __launch_bounds__(QP_THREADS) void qr_panel_kernel(int n, double *__r
 // A column swap j <-> jm moves 2 x 256 doubles through LDS between the 8 owner lanes of each
 // column.  The pivot rule is the reference's (norms from the updated matrix, first maximum).
 constexpr int QT_THREADS = 512;
+#ifndef QT_GB
+#define QT_GB 4  // slot-0 requests in flight per lane; must divide 4 (a region's first row block is 4 KB0).  The loop over
+                 // the groups stays rolled: unrolled, the register allocator spills ten times as much
+#endif
+static_assert(4 % QT_GB == 0, "QT_GB must divide 4: groups start at row block 4 * KB0");
 constexpr int QT_LSTRIDE = 264;  // LDS column stride in doubles (bank-conflict-free for 4 column groups)
 constexpr int QT_VS = 34;        // stride of the per-row-group reflector slices (conflict-free 16-byte broadcasts)
 
@@ -536,12 +541,16 @@ __device__ __forceinline__ void qt_reg_col(double (&x)[32], const double *vq, do
 }
 
 // KB0 = j / 32: first row block (4 k = 32 rows) that still has unfinished rows
-template <int KB0>
-__device__ __forceinline__ void qt_step(int n, int j, double *__restrict__ A, double *__restrict__ tau,
+// FULLN: n == 256, known at compile time: every `row < n` folds away.  With a run-time n each of the 32 global loads of the
+// memory-resident slot sat in a branch of its own with a full wait behind it (32 trips to the L2 per pass, three passes
+// per step during the first 64 steps: ~17 us per step against ~6 us for the later ones).
+template <int KB0, bool FULLN>
+__device__ __forceinline__ void qt_step(int n_rt, int j, double *__restrict__ A, double *__restrict__ tau,
                                         double *Lc, double *colP, double *colJ, double *vbuf, double *nrmp,
                                         double *dummy, int *pv, double *cand_v, int *cand_i, double (&x2)[32],
                                         double (&x3)[32])
 {
+    const int n = FULLN ? 256 : n_rt;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, rg = lane & 7, cg = lane >> 3;
     const int pb = 8 * w + cg;                          // position of slot s is 64 s + pb
     double *g0 = A + (long)n * pb;                      // slot 0: in place in global memory
@@ -687,20 +696,49 @@ __device__ __forceinline__ void qt_step(int n, int j, double *__restrict__ A, do
     }
     if (KB0 < 2 && 8 * w + 7 > j) {       // slot 0: in place in global memory (L2), the column is read twice
         double d = 0.0;
+        if (FULLN) {
+            // QT_GB requests in flight at a time, by hand: at its register limit the compiler requests, waits and
+            // accumulates one element after the other (32 trips to the L2 per pass)
+#pragma unroll 1
+            for (int k0 = 4 * KB0; k0 < 32; k0 += QT_GB) {
+                double t[QT_GB];
+#pragma unroll
+                for (int i = 0; i < QT_GB; ++i) t[i] = __builtin_nontemporal_load(g0 + rg + 8 * (k0 + i));
+#pragma unroll
+                for (int i = 0; i < QT_GB; ++i) d = __builtin_fma(vq[k0 + i], t[i], d);
+            }
+        } else {
 #pragma unroll 16
-        for (int k = 4 * KB0; k < 32; ++k) {
-            const int r = rg + 8 * k;
-            d += vq[k] * (r < n ? g0[r] : 0.0);
+            for (int k = 4 * KB0; k < 32; ++k) {
+                const int r = rg + 8 * k;
+                d += vq[k] * (r < n ? g0[r] : 0.0);
+            }
         }
         const double wv = (pb > j) ? sum8(d) * tj : 0.0;
         double nr = 0.0;
+        if (FULLN) {
+#pragma unroll 1
+            for (int k0 = 4 * KB0; k0 < 32; k0 += QT_GB) {
+                double t[QT_GB];
+#pragma unroll
+                for (int i = 0; i < QT_GB; ++i) t[i] = g0[rg + 8 * (k0 + i)];
+#pragma unroll
+                for (int i = 0; i < QT_GB; ++i) {
+                    const int r = rg + 8 * (k0 + i);
+                    const double y = t[i] - vq[k0 + i] * wv;
+                    g0[r] = y;
+                    nr += (r > j ? 1.0 : 0.0) * (y * y);
+                }
+            }
+        } else {
 #pragma unroll 16
-        for (int k = 4 * KB0; k < 32; ++k) {
-            const int r = rg + 8 * k;
-            if (r < n) {
-                const double y = g0[r] - vq[k] * wv;
-                g0[r] = y;
-                nr += (r > j ? 1.0 : 0.0) * (y * y);
+            for (int k = 4 * KB0; k < 32; ++k) {
+                const int r = rg + 8 * k;
+                if (r < n) {
+                    const double y = g0[r] - vq[k] * wv;
+                    g0[r] = y;
+                    nr += (r > j ? 1.0 : 0.0) * (y * y);
+                }
             }
         }
         nrmp[rg * 256 + pb] = nr;
@@ -708,7 +746,8 @@ __device__ __forceinline__ void qt_step(int n, int j, double *__restrict__ A, do
     __syncthreads();
 }
 
-__global__ __launch_bounds__(QT_THREADS) void qr_tile256_kernel(int n, int nsteps, double *__restrict__ Aall, long strideA,
+template <bool FULLN>
+__global__ __launch_bounds__(QT_THREADS) void qr_tile256_kernel(int n_rt, int nsteps, double *__restrict__ Aall, long strideA,
                                                                double *__restrict__ tauall,
                                                                int *__restrict__ pivall,
                                                                const double *__restrict__ srcall, long strideSrc,
@@ -717,6 +756,7 @@ __global__ __launch_bounds__(QT_THREADS) void qr_tile256_kernel(int n, int nstep
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     if (guard && guard[0] != guard_val) return;  // fallback use, see qr_pivot_kernel
+    const int n = FULLN ? 256 : n_rt;
     if (srcall) {
         const double *__restrict__ src = srcall + (long)blockIdx.x * strideSrc;
         double *__restrict__ dst = Aall + (long)blockIdx.x * strideA;
@@ -767,7 +807,7 @@ __global__ __launch_bounds__(QT_THREADS) void qr_tile256_kernel(int n, int nstep
     // eight regions of 32 steps, each with its compile-time first live row block
 #define QT_REGION(REG)                                             \
     for (int j = 32 * (REG); j < nsteps && j < 32 * (REG) + 32; ++j) \
-        qt_step<(REG)>(n, j, A, tau, Lc, colP, colJ, vbuf, nrmp, dummy, pv, cand_v, cand_i, x2, x3);
+        qt_step<(REG), FULLN>(n, j, A, tau, Lc, colP, colJ, vbuf, nrmp, dummy, pv, cand_v, cand_i, x2, x3);
     QT_REGION(0) QT_REGION(1) QT_REGION(2) QT_REGION(3) QT_REGION(4) QT_REGION(5) QT_REGION(6) QT_REGION(7)
 #undef QT_REGION
     if (tid < n) piv[tid] = pv[tid];
@@ -2037,7 +2077,9 @@ static hipError_t launch_qr_single(int n, int n_units, double *A, long strideA, 
         (void)hipGetDevice(&dev);
         static unsigned attr_mask = 0;  // per device
         if (!(attr_mask & (1u << dev))) {
-            (void)hipFuncSetAttribute((const void *)qr_tile256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+            (void)hipFuncSetAttribute((const void *)qr_tile256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds_t);
+            (void)hipFuncSetAttribute((const void *)qr_tile256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds_t);
             attr_mask |= 1u << dev;
         }
@@ -2045,8 +2087,12 @@ static hipError_t launch_qr_single(int n, int n_units, double *A, long strideA, 
         // the first 128 steps, qr_tail_kernel the rest; `never` is a word that never equals -1 (the tail's exit test)
         const bool two_phase = X && never && n == 256 && !guard;
         const int nsteps = two_phase ? 128 : n;
-        hipLaunchKernelGGL(qr_tile256_kernel, dim3(n_units), dim3(QT_THREADS), lds_t, s, n, nsteps, A, strideA, tau, pivot,
-                           src, strideSrc, guard, guard_val, two_phase ? X : nullptr, strideX);
+        if (n == 256 && !getenv("DQMC_QR_TILE_BOUNDS"))
+            hipLaunchKernelGGL(qr_tile256_kernel<true>, dim3(n_units), dim3(QT_THREADS), lds_t, s, n, nsteps, A, strideA, tau,
+                               pivot, src, strideSrc, guard, guard_val, two_phase ? X : nullptr, strideX);
+        else
+            hipLaunchKernelGGL(qr_tile256_kernel<false>, dim3(n_units), dim3(QT_THREADS), lds_t, s, n, nsteps, A, strideA, tau,
+                               pivot, src, strideSrc, guard, guard_val, two_phase ? X : nullptr, strideX);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess || !two_phase) return e;
         hipLaunchKernelGGL((qr_tail_kernel<128, 4>), dim3(n_units), dim3(256), 0, s, n_units, X, strideX, A, strideA, tau, pivot,
@@ -2287,8 +2333,17 @@ __global__ __launch_bounds__(16) void trsm_diag_inv_kernel(int n, const double *
     const double *__restrict__ dmul = dmulall ? dmulall + (long)unit * sV : nullptr;
     double *__restrict__ W = Wall + ((long)unit * nblk + J) * 256;
     const int col = j0 + j;
-    for (int i = 0; i < 16; ++i) B[i][j] = (col < n && j0 + i < n && i < j) ? T[(j0 + i) + (long)n * col] : 0.0;
-    rdg[j] = col < n ? (dmul ? dmul[col] : 1.0 / T[col + (long)n * col]) : 1.0;
+    {   // sixteen requests in flight, then the bounds as selects (as a conditional load each one waits for the one before)
+        const int cc = min(col, n - 1);
+        double bv[16], dv;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bv[i] = T[min(j0 + i, n - 1) + (long)n * cc];
+        dv = dmul ? dmul[cc] : T[cc + (long)n * cc];
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 16; ++i) B[i][j] = (col < n && j0 + i < n && i < j) ? bv[i] : 0.0;
+        rdg[j] = col < n ? (dmul ? dv : 1.0 / dv) : 1.0;
+    }
     __syncthreads();
     double wcol[16];
 #pragma unroll

@@ -58,10 +58,10 @@ __global__ __launch_bounds__(256) void trsm_rl_kernel(int nr, int n, int c0, int
 
     TR_STAMP(0);
     // my tiles: block L = 2 t + par; element [4 r + g][ci] = X[row][c0 + 16 L + 4 r + g]
-    // All 32 pivot entries first, then the 32 gathered columns, and the bounds applied as a 0/1 FACTOR: with
-    // `ok ? v : 0.0` the compiler sinks every load into an exec-mask branch of its own and waits for it at the merge
+    // All 32 pivot entries first, then the 32 gathered columns, each load pinned in front of its bound test: with a plain
+    // `ok ? A[..] : 0.0` the compiler sinks every load into an exec-mask branch of its own and waits for it at the merge
     // (s_waitcnt vmcnt(0)) - 32 trips to the L2 one after the other, 37 k cycles of a 120 k cycle kernel (stamps,
-    // tools/tr_stamps.py).  Addresses are clamped, so what is multiplied by 0 is a finite matrix element.
+    // tools/tr_stamps.py).  Addresses are clamped, so the unconditional loads stay inside the matrix.
     d4_t x[8];
     int pjv[8][4];
 #pragma unroll
@@ -72,13 +72,17 @@ __global__ __launch_bounds__(256) void trsm_rl_kernel(int nr, int n, int c0, int
             pjv[t][r] = piv ? piv[c0 + cc] : c0 + cc;
         }
 #pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[t][r] = A[(unsigned)(rowc + ld * pjv[t][r])];
+    asm volatile("" ::: "memory");  // the 32 loads stay in front of the bound tests (see above), which are then plain selects
+#pragma unroll
     for (int t = 0; t < 8; ++t) {
         const int L = 2 * t + par;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int col = 16 * L + 4 * r + g;
-            const double v = A[(unsigned)(rowc + ld * pjv[t][r])];
-            x[t][r] = v * ((L < nblk && col < n && row < nr) ? 1.0 : 0.0);
+            x[t][r] = (L < nblk && col < n && row < nr) ? x[t][r] : 0.0;
         }
     }
 #ifdef TR_STAMPS
