@@ -1037,11 +1037,16 @@ __device__ __forceinline__ void flush_lu_body(int bid, int n, int n_units, const
         if (FULL) {
             // (a wave's request covers 2 columns x 512 contiguous bytes = 8 cache lines; one column per 4 lanes with 16
             // doubles each touched 64 lines per request)
+            d2v rv[8];  // (requests first, LDS stores after: written as load-store pairs they are waited for one by one)
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int pc = i * 256 + tid, col = pass * 64 + (pc >> 5), w2 = 2 * (pc & 31);
-                *reinterpret_cast<d2v *>(Rl + col * FL_LDR + w2) =
-                    *reinterpret_cast<gcd2p>(Gin + (long)n * (n0 + col) + site0 + w2);
+                rv[i] = *reinterpret_cast<gcd2p>(Gin + (long)n * (n0 + col) + site0 + w2);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int pc = i * 256 + tid, col = pass * 64 + (pc >> 5), w2 = 2 * (pc & 31);
+                *reinterpret_cast<d2v *>(Rl + col * FL_LDR + w2) = rv[i];
             }
         } else {
             for (int i = 0; i < 16; ++i)
@@ -1155,11 +1160,16 @@ __device__ __forceinline__ void flush_lu_body(int bid, int n, int n_units, const
                 const int tl = pass * 64 + (tid >> 2), tp = n0 + tl, s0 = (tid & 3) * 16;
                 double *d = Rl + tl * FL_LDR + s0;
                 if (FULL) {
+                    d2v rv[8];
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const int pc = i * 256 + tid, col = pass * 64 + (pc >> 5), w2 = 2 * (pc & 31);
-                        *reinterpret_cast<d2v *>(Rl + col * FL_LDR + w2) =
-                            *reinterpret_cast<gcd2p>(Gin + (long)n * (n0 + col) + site0 + w2);
+                        rv[i] = *reinterpret_cast<gcd2p>(Gin + (long)n * (n0 + col) + site0 + w2);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int pc = i * 256 + tid, col = pass * 64 + (pc >> 5), w2 = 2 * (pc & 31);
+                        *reinterpret_cast<d2v *>(Rl + col * FL_LDR + w2) = rv[i];
                     }
                 } else {
                     for (int i = 0; i < 16; ++i)
