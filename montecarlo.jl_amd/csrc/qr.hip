@@ -293,12 +293,18 @@ __global__ __launch_bounds__(QP_THREADS) void qr_panel_kernel(int n, double *__r
             for (int kk = 0; kk < QP_NB; ++kk) fj[kk] = kk < k ? F[kk * n + jm] : 0.0;
 #pragma unroll
             for (int e = 0; e < QP_RPT; ++e) {
-                const int r = tid + QP_THREADS * e, rc = min(r, n - 1);
-                a[e] = A[rc + (long)n * jm];
-                bold[e] = A[rc + (long)n * j];
+                const int r = tid + QP_THREADS * e;
+                int rc = min(r, n - 1);
+                // 32-bit element offsets from the matrix's scalar base, recomputed in every step (rc is made opaque): the
+                // 34 addresses of this block are invariant inside a panel, the compiler hoisted them out of the step loop,
+                // spilled them, and every request then waited for the reload of its own address - 15 trips to the L2
+                // one after the other in every step
+                asm volatile("" : "+v"(rc));
+                a[e] = A[(unsigned)(rc + n * jm)];
+                bold[e] = A[(unsigned)(rc + n * j)];
                 double vp[QP_NB];
 #pragma unroll
-                for (int kk = 0; kk < QP_NB; ++kk) vp[kk] = A[rc + (long)n * (j0 + min(kk, kb - 1))];
+                for (int kk = 0; kk < QP_NB; ++kk) vp[kk] = A[(unsigned)(rc + n * (j0 + min(kk, kb - 1)))];
 #pragma unroll
                 for (int kk = 0; kk < QP_NB; ++kk) a[e] -= (r >= j ? fj[kk] : 0.0) * vp[kk];
                 sq += (r < n && r >= j) ? a[e] * a[e] : 0.0;
