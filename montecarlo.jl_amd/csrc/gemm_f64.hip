@@ -195,16 +195,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, int tiles_m, int 
     load(0, ra[0], rb[0], ksd[0], ksc[0]);
     store(0, ra[0], rb[0], ksd[0], ksc[0]);
     GEMM_LDS_BARRIER();
-    if (nk > 1) load(1, ra[1], rb[1], ksd[1], ksc[1]);
+    // (the requests are unconditional - past the last tile they fetch it again, harmlessly: behind `if (kt + 2 < nk)` the
+    // compiler cannot count the requests in flight at the merge and waits for ALL of them before a tile goes to LDS,
+    // i.e. also for the tile requested a moment ago - the ring was one tile deep, not two)
+    load(min(1, nk - 1), ra[1], rb[1], ksd[1], ksc[1]);
     for (int kt = 0; kt < nk; kt += 2) {
         // even tile kt: LDS buffer 0, its registers (slot 0) are free for tile kt+2
-        if (kt + 2 < nk) load(kt + 2, ra[0], rb[0], ksd[0], ksc[0]);
+        load(min(kt + 2, nk - 1), ra[0], rb[0], ksd[0], ksc[0]);
         compute(0);
         if (kt + 1 < nk) store(1, ra[1], rb[1], ksd[1], ksc[1]);
         GEMM_LDS_BARRIER();
         if (kt + 1 >= nk) break;
         // odd tile kt+1: LDS buffer 1, slot 1 free for tile kt+3
-        if (kt + 3 < nk) load(kt + 3, ra[1], rb[1], ksd[1], ksc[1]);
+        load(min(kt + 3, nk - 1), ra[1], rb[1], ksd[1], ksc[1]);
         compute(1);
         if (kt + 2 < nk) store(0, ra[0], rb[0], ksd[0], ksc[0]);
         GEMM_LDS_BARRIER();
