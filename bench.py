@@ -347,8 +347,11 @@ def main():
                 ent["pmc_source"] = pmc.get("_file")
         if fam == "gemm" and pmc:
             busy, cyc = pmc_sum(("slab_chain",), "SQ_VALU_MFMA_BUSY_CYCLES"), pmc_sum(("slab_chain",), "SQ_BUSY_CYCLES")
-            if busy and cyc:  # MFMA-pipe busy cycles per SIMD-busy cycle (both summed over the chip), slab kernel
-                ent["mfma_busy_frac"] = busy / (4.0 * cyc)
+            if busy and cyc:
+                # slab kernel: SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs, SQ_BUSY_CYCLES over the 32 shader
+                # engines (8 XCDs x 4): (busy / 1024) / (cyc / 32).  Cross-check: 0.74 for the slab kernel's 52 TF/s
+                # against the 71 - 77 TF/s of the MFMA-only probe.  (Round-3 profiles before this fix divided by 4: > 1.)
+                ent["mfma_busy_frac"] = busy / (32.0 * cyc)
                 ent["pmc_source"] = pmc.get("_file")
         kernels.append(ent)
     # HBM-side traffic of one full GEMM launch: PMC passes cannot run inside this process; the number comes from the
