@@ -74,19 +74,37 @@ __global__ __launch_bounds__(256) void slab_chain_kernel(SlabArgs a)
     };
 #pragma unroll
     for (int i = 0; i < SL_RING - 1; ++i) issue(i);  // first A operands in flight (HBM latency) before X_0 is staged
-    // ---- X_0 slab -> LDS, scaled by pre_1
+    // ---- X_0 slab -> LDS, scaled by pre_1.  All sixteen requests of a thread (and the 32 HS-field bytes of its rows, as
+    // four 8-byte words) are in flight together: written as load - scale - store per element, each element waited for
+    // its own trip to the L2 (the field byte sat behind a branch): sixteen trips before the first product could start.
     {
         const double *X0 = a.X0 + (long)unit * a.x_su + (long)blk * a.x_sb + (long)SL_N * (SL_W * slab);
         const int col = tid >> 3, r0 = 32 * (tid & 7);
         const int8_t *pc = a.st[0].pre_conf ? a.st[0].pre_conf + conf_off : nullptr;
+        typedef double d2x __attribute__((ext_vector_type(2)));
+        d2x xv[16];
 #pragma unroll
-        for (int i = 0; i < 32; i += 2) {
-            double2 v = *reinterpret_cast<const double2 *>(X0 + (long)SL_N * col + r0 + i);
+        for (int i = 0; i < 16; ++i) xv[i] = *reinterpret_cast<const d2x *>(X0 + (long)SL_N * col + r0 + 2 * i);
+        // (rows r0 .. r0 + 31 of the field: r0 is a multiple of 32 and a slice starts on a multiple of SL_N bytes)
+        const unsigned long long *pw = reinterpret_cast<const unsigned long long *>(pc ? pc + r0 : reinterpret_cast<const int8_t *>(X0));
+        unsigned long long cw[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) cw[i] = pw[i];
+        asm volatile("" ::: "memory");
+        const bool sp = a.st[0].pre_sign > 0, bn = blk != 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            double fx = 1.0, fy = 1.0;
             if (pc) {
-                v.x *= slab_conf_val(pc, r0 + i, a.st[0].pre_sign, blk, a.epl, a.eml);
-                v.y *= slab_conf_val(pc, r0 + i + 1, a.st[0].pre_sign, blk, a.epl, a.eml);
+                const int8_t b0 = (int8_t)(cw[(2 * i) >> 3] >> (8 * ((2 * i) & 7)));
+                const int8_t b1 = (int8_t)(cw[(2 * i + 1) >> 3] >> (8 * ((2 * i + 1) & 7)));
+                fx = (((b0 > 0) == sp) != bn) ? a.epl : a.eml;
+                fy = (((b1 > 0) == sp) != bn) ? a.epl : a.eml;
             }
-            *reinterpret_cast<double2 *>(buf0 + col * SL_LD + r0 + i) = v;
+            d2x v = xv[i];
+            v.x *= fx;
+            v.y *= fy;
+            *reinterpret_cast<d2x *>(buf0 + col * SL_LD + r0 + 2 * i) = v;
         }
     }
     __syncthreads();
