@@ -1486,8 +1486,7 @@ hipError_t launch_sweep_flush_lu(int n, int n_units, const double *Gin, double *
     // In-kernel stamps (tools/fl_stamps.py): 38 k cycles until the operands of a workgroup are there, 8 - 10 k of solves,
     // 12 - 16 k per pass of 4 k cycles of MFMA - all resident workgroups fetch at ~17 B/cycle/CU, which is what the part
     // delivers to every CU at once; PMC: HBM traffic = algorithmic (profiles/r03_pmc_flush_512units.txt))
-    const bool nt8_env = getenv("DQMC_FLUSH_NT8") != nullptr;  // the former form, for A/B
-    if (ncp2 && wide && full && n % 256 == 0 && (nt8_env || ncp2_env)) {
+    if (ncp2 && wide && full && n % 256 == 0 && ncp2_env) {  // (the former form: DQMC_FLUSH_NCP2, for A/B and under test)
         static unsigned m2 = 0;
         if (!(m2 & (1u << dev))) {
             (void)hipFuncSetAttribute((const void *)sweep_flush_lu_kernel<true, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,

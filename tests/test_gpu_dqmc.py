@@ -245,12 +245,13 @@ def test_cooperative_qr_timeout_falls_back(gpu, O):
                                    {"DQMC_SWEEP_PERSIST": "1", "DQMC_SLICE_AGENT": "1"},
                                    {"DQMC_OVERLAP": "1"},
                                    {"DQMC_OVERLAP": "1", "DQMC_OVERLAP_RDIVP": "1", "DQMC_CHAIN_AHEAD": "1"},
-                                   {"DQMC_QR_ROWS": "1"}],
+                                   {"DQMC_QR_ROWS": "1"}, {"DQMC_TRSM_BOUNDS": "1"},
+                                   {"DQMC_QR_NOCOOP": "1", "DQMC_QR_TILE_BOUNDS": "1"}],
                          ids=["slab_chains", "fused_sweep", "two_phase_qr", "two_pass_flush", "qr_sc1_mailbox",
                               "qr_tile_plus_tail", "qr_tile_only", "trsm_left_looking", "trsm_substitution",
                               "sweep_round1", "sweep_one_wave", "sweep_one_launch_per_slice", "sweep_one_launch_agent_fences",
                               "aux_stream_overlap",
-                              "aux_stream_all", "qr_row_split"])
+                              "aux_stream_all", "qr_row_split", "trsm_with_bounds", "qr_tile_with_bounds"])
 def test_fast_paths_against_their_plain_forms(gpu, plain):
     """The default launch forms at n = 256 (slab-resident product chains, elimination fused with the previous chunk's
     flush, two-phase QR; the two-pass flush of the throughput regime against the one-pass one) against the forms they
