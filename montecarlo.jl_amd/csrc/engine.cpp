@@ -110,6 +110,7 @@ struct dqmc_handle {
     long long fam_n[DQMC_K_COUNT] = {0};
     std::vector<void *> allocs;
     QrCoopWorkspace qr_ws;
+    int qrb_sites = 0;  // call sites of udt_AVX_pivot! that take the one-launch blocked form (DQMC_QRB_SITES)
     // checkerboard products with sparse bond-group factors (cb.hip); the dense constants above stay valid
     struct {
         bool on = false;
@@ -335,6 +336,19 @@ static int alloc_qr_workspace(dqmc_handle *h)
     h->qr_ws.rows = getenv("DQMC_QR_ROWS") != nullptr && qr_rows_blocks_per_cu() >= 1;
     if (const char *e = getenv("DQMC_QR_FORCE_TIMEOUT"))
         h->qr_ws.force_timeout = strncmp(e, "step:", 5) == 0 ? 2 + atoi(e + 5) : 1;
+    // pre-pivoted blocked UDT in one launch (qrb.hip): n == 256, all eight workgroups of every unit co-resident.
+    // DQMC_QR_NOBLOCKED: off; DQMC_QRB_SITES: bit mask of the call sites that use it (1 = slice-sequence builds and every other
+    // caller, 2 = first, 4 = second factorisation of calculate_greens_AVX!)
+    h->qrb_sites = 0;
+    if (h->n == 256 && getenv("DQMC_QR_NOBLOCKED") == nullptr) {
+        const int per_cu = qrb_blocks_per_cu();
+        if (per_cu >= 1 && ((h->units + 7) / 8) * 64 <= prop.multiProcessorCount * per_cu) {
+            CHK(dalloc(h, (char **)&h->qr_ws.mailbox2, qrb_mailbox_bytes(h->units)));
+            h->qr_ws.blk_max_blocks = prop.multiProcessorCount * per_cu;
+            h->qrb_sites = 7;
+            if (const char *e = getenv("DQMC_QRB_SITES")) h->qrb_sites = atoi(e) & 7;
+        }
+    }
     return 0;
 }
 static int check_qr_workspace(dqmc_handle *h)
@@ -344,6 +358,9 @@ static int check_qr_workspace(dqmc_handle *h)
     HIPCHK(hipMemcpy(&e, h->qr_ws.errflag, sizeof(int), hipMemcpyDeviceToHost));
     if (e) {  // reported once: the flag is cleared, the data of the failed call is not trustworthy
         HIPCHK(hipMemset(h->qr_ws.errflag, 0, sizeof(int)));
+        if (e & 16)
+            return fail(h, DQMC_ERR_HIP, "blocked UDT: a hand-off between the workgroups of a matrix timed out (results of this call "
+                                         "are invalid; DQMC_QR_NOBLOCKED=1 selects the kernels without that requirement)");
         return fail(h, DQMC_ERR_HIP, (e & 8) ? "site sweep (one launch per slice): a hand-over between workgroups timed out - the grid was "
                                                "not co-resident (results of this call are invalid; the default launch-per-chunk form has no "
                                                "such requirement)"
@@ -418,8 +435,17 @@ static int udt_formq(dqmc_handle *h, double *Uout, QrSet &q, double *winv, doubl
     CHK(run_gemm(h, g));
     return 0;
 }
+// n == 256: the whole of udt_AVX_pivot! in one launch, pivot order fixed up front (qrb.hip).  site: see DQMC_QRB_SITES
+static bool udt_is_fused(const dqmc_handle *h, int site) { return (h->qrb_sites >> site) & 1; }
+static int udt_fused(dqmc_handle *h, const double *A, double *Uout, double *Dout, double *Tout, int apply, QrSet &q)
+{
+    Timed t(h, DQMC_K_QR);
+    HIPCHK(launch_udt_blocked(h->units, A, h->nn, Uout, h->nn, Dout, h->n, Tout, h->nn, q.pivot, &h->qr_ws, apply, h->cur));
+    return 0;
+}
 static int udt(dqmc_handle *h, double *A, double *Uout, double *Dout, double *Tout, int apply)
 {
+    if (udt_is_fused(h, 0) && Tout && Tout != A) return udt_fused(h, A, Uout, Dout, Tout, apply, h->qs[0]);
     CHK(udt_factor(h, A, Dout, Tout, apply, h->qs[0]));
     return udt_formq(h, Uout, h->qs[0], h->qs[0].winv, h->qs[0].ts);
 }
@@ -452,22 +478,33 @@ static int calculate_greens_src(dqmc_handle *h, double *out, Udt L, Udt R)
     g.colscale = vs_arr(R.d, n);
     g.rowscale = vs_arr(L.d, n);
     CHK(run_gemm(h, g));
+    if (udt_is_fused(h, 1)) {                                          // :349 in one launch (T out of place, in qa.W)
+        CHK(udt_fused(h, out, h->Tr, h->Dr, qa.W, 0, qa));
+        CHK(aux_join(h));
+        CHK(rdivp_set(h, R.u, qa.W, h->Ur, qa, qa.winv, qa.ts));       // :361
+    } else {
     CHK(udt_factor(h, out, h->Dr, nullptr, 0, qa));                    // :349, first half
     CHK(aux_join(h));                                                  // L.u / R.u of a slot whose Q was still being formed
     if (ov) CHK(aux_begin(h));                                         // :361 (out of place: Ur = R.u[:, p] / T)
     CHK(rdivp_set(h, R.u, out, h->Ur, qa, ov ? winv_x : qa.winv, ov ? ts_x : qa.ts));
     if (ov) aux_end(h);
     CHK(udt_formq(h, h->Tr, qa, qa.winv, qa.ts));                      // :349, second half
+    }
     CHK(run_gemm(h, gemm_base(h, U_(h, L.u), 0, U_(h, h->Tr), 0, h->Tl)));    // :360
     CHK(aux_join(h));
     g = gemm_base(h, U_(h, h->Tl), 1, U_(h, h->Ur), 0, h->Tr);         // :362 + :368
     g.adddiag = vs_arr(h->Dr, n);
     CHK(run_gemm(h, g));
+    if (udt_is_fused(h, 2)) {                                          // :376 in one launch
+        CHK(udt_fused(h, h->Tr, h->Ul, h->Dr, qb.W, 0, qb));
+        CHK(rdivp_set(h, h->Ur, qb.W, h->Ur, qb, qb.winv, qb.ts));     // :377
+    } else {
     CHK(udt_factor(h, h->Tr, h->Dr, nullptr, 0, qb));                  // :376
     if (ov) CHK(aux_begin(h));
     CHK(rdivp_set(h, h->Ur, h->Tr, h->Ur, qb, ov ? winv_x : qb.winv, ov ? ts_x : qb.ts));  // :377
     if (ov) aux_end(h);
     CHK(udt_formq(h, h->Ul, qb, qb.winv, qb.ts));
+    }
     CHK(aux_join(h));                                                  // (the next product overwrites Tr = T of :376)
     CHK(run_gemm(h, gemm_base(h, U_(h, h->Tl), 0, U_(h, h->Ul), 0, h->Tr)));  // :378
     g = gemm_base(h, U_(h, h->Ur), 0, U_(h, h->Tr), 1, out);           // :382-391
@@ -638,11 +675,15 @@ static int add_slice_sequence(dqmc_handle *h, int dir, int idx, bool wrap_temp)
     // new factors into the spare, then slot dst <-> spare: the old slot dst stays readable.  The Q of the new slot is
     // not needed before the second product of calculate_greens_AVX!: it is formed on the auxiliary stream
     const int sp = h->K + 1;
-    CHK(udt_factor(h, out, dslot(h, sp), h->tmp2, 1, h->qs[0]));
-    CHK(aux_begin(h));
-    const int rc = udt_formq(h, uslot(h, sp), h->qs[0], h->qs[0].winv, h->qs[0].ts);
-    aux_end(h);
-    CHK(rc);
+    if (udt_is_fused(h, 0)) {
+        CHK(udt_fused(h, out, uslot(h, sp), dslot(h, sp), h->tmp2, 1, h->qs[0]));
+    } else {
+        CHK(udt_factor(h, out, dslot(h, sp), h->tmp2, 1, h->qs[0]));
+        CHK(aux_begin(h));
+        const int rc = udt_formq(h, uslot(h, sp), h->qs[0], h->qs[0].winv, h->qs[0].ts);
+        aux_end(h);
+        CHK(rc);
+    }
     CHK(run_gemm(h, gemm_base(h, U_(h, h->tmp2), 0, U_(h, tslot(h, src)), 0, tslot(h, sp))));
     slot_swap_spare(h, dst);
     return 0;
@@ -1967,7 +2008,8 @@ int dqmc_udt_pivot(int32_t device_id, int32_t n, int32_t batch, double *U, doubl
     SCHK(check_qr_workspace(h));
     SHIP(hipMemcpy(U, dU, un * sizeof(double), hipMemcpyDeviceToHost));
     SHIP(hipMemcpy(D, dD, uv * sizeof(double), hipMemcpyDeviceToHost));
-    SHIP(hipMemcpy(T, apply ? dTo : dT, un * sizeof(double), hipMemcpyDeviceToHost));
+    // (the one-launch form writes T out of place also for Val(false))
+    SHIP(hipMemcpy(T, (apply || udt_is_fused(h, 0)) ? dTo : dT, un * sizeof(double), hipMemcpyDeviceToHost));
     std::vector<int> piv(uv);
     SHIP(hipMemcpy(piv.data(), h->pivot, uv * sizeof(int), hipMemcpyDeviceToHost));
     for (size_t i = 0; i < uv; ++i) pivot[i] = (int64_t)piv[i] + 1;

@@ -120,7 +120,16 @@ struct QrCoopWorkspace {
     int rows = 0;           // DQMC_QR_ROWS: n == 256 two-phase form with the row-split first phase (qr_rows_kernel)
     int force_timeout = 0;  // DQMC_QR_FORCE_TIMEOUT: 1 = every cooperative launch gives up at once;
                             // "step:<j>" -> 2 + j: part 3 of every matrix stops publishing at step j (bounded spins run out)
+    // pre-pivoted blocked UDT (qrb.hip, n == 256): its own mailbox; blk_max_blocks = co-resident workgroups (0 = off)
+    double *mailbox2 = nullptr;
+    int blk_max_blocks = 0;
 };
+// udt_AVX_pivot! (UDT.jl:192-306) at n == 256 in one launch: U, D, T = D^-1 R (pivot applied or not, out of place), pivot
+// (0-based positions -> original columns).  Pivot order = descending norm of the input columns (qrb.hip).
+hipError_t launch_udt_blocked(int n_units, const double *A, long strideA, double *U, long strideU, double *D, long strideD,
+                              double *T, long strideT, int *pivot, QrCoopWorkspace *ws, int apply_pivot, hipStream_t s);
+size_t qrb_mailbox_bytes(int n_units);
+int qrb_blocks_per_cu();
 // ws may be null: single-workgroup kernels only
 // W (n_units x strideW, may be null): output of the cooperative kernel, which leaves A intact so that a time-out of
 // its hand-offs can be recovered by the single-workgroup kernel launched (guarded) behind it; *factored tells where

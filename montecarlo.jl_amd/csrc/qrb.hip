@@ -1,0 +1,731 @@
+// qrb.hip — udt_AVX_pivot! (src/linalg/UDT.jl:192-306) for n = 256 as ONE launch: a blocked Householder QR whose pivot
+// order is fixed up front (round 4).
+//
+// What it replaces: the reference's loop (UDT.jl:212-246) searches the largest trailing column at each of its n steps; on
+// the device that was 256 dependent steps with two inter-workgroup hand-offs each (qr_coop_kernel + qr_tail_kernel), followed by
+// five more launches for D, T and Q (udt_finish, V'V, TRSM, Q GEMM).  Here the column order is taken ONCE, from the norms of the
+// input (descending, first maximum first - the order the reference's first step would start from), and then
+//   * the 256 sorted columns are 8 panels of 32; workgroup w of the matrix OWNS panel w (owner computes: no column ever moves),
+//   * a panel is factored inside its workgroup with no hand-off at all (one LDS-only barrier per step), while a fifth wave
+//     scales the reflectors, accumulates the panel's compact-WY triangle T_w column by column (dlarft recurrence; the dot products
+//     V[:,0:j]' v_j it needs fall out of the step for free: they are what the FINISHED columns' lanes compute anyway) and
+//     publishes V_w, T_w and diag R as self-validating tagged granules,
+//   * every other workgroup applies the block reflector (I - V T' V') to its own columns with v_mfma_f64_16x16x4_f64, the columns
+//     living in MFMA ACCUMULATOR layout for the whole kernel: an accumulator register is at the same time the B operand of
+//     W = V' C, so nothing moves between lanes (C/D: row = (lane>>4) + 4 reg, col = lane & 15; B: k = lane>>4),
+//   * Q is accumulated on the way: every workgroup also carries Z = its 32 columns of Q' = H_7' ... H_0' E through the same
+//     block reflectors (in the time it would otherwise wait for the next panel), so U = Q costs no pass of its own,
+//   * D = |diag R| and T = D^-1 R (pivot applied or not, UDT.jl:283-306) are written by the panel's owner.
+// 8 hand-offs per factorisation instead of 2 x 128 + 128 steps, one launch instead of eight.
+//
+// Same Householder vectors, tau, R as an unblocked factorisation of the pre-sorted matrix (compact-WY is a reassociation);
+// the reference's own column order differs (it re-evaluates the norms at every step).  G is unaffected to ~1e-12 at config 3
+// (measured with the CPU checker's pre-sort study switch); parity is asserted on G / the HS field against the
+// reference-rule oracle and on U, D, T against the oracle run with the same pre-sorted order.
+//
+// Hand-offs: granule = 16 bytes {low half, tag, high half, tag}, written / read as two 8-byte relaxed atomics, tag = launch
+// epoch (the mailbox is never cleared).  A reader that sees both tags has the payload: no flag, no fence.  Stores are
+// workgroup-scope (they stay in the XCD's L2) only after the eight workgroups have verified at run time that they share one XCD
+// (HW_REG_XCC_ID exchanged through agent-scope granules); otherwise agent-scope (write-through).  Loads are always agent-scope
+// (L1-bypassing).  Every spin is bounded; a time-out raises errflag bit 4 (the caller's results are invalid and it is told so).
+// A workgroup only ever waits for LOWER parts of its own matrix, so with in-order dispatch the wait always ends.
+#include "kernels.h"
+
+namespace dqmc {
+namespace {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef unsigned long long qword;
+
+constexpr int QB_THREADS = 256;  // one wave per SIMD: 512 registers per lane
+constexpr int VLD = 260;         // LDS column stride of a staged panel (doubles): (nn, kq) operand reads spread over the banks
+constexpr int TLD = 36;
+constexpr int UST = 34;          // stride of the per-row-group slices of a step's reflector (conflict-free 16-byte broadcasts)
+constexpr unsigned QB_SPIN = 1000000u;  // ~1 s of polling: far beyond any legitimate wait (a whole factorisation is ~0.2 ms)
+
+// mailbox of one unit, in granules
+constexpr long MB_V = 0;                    // [panel 8][column 32][row 256]
+constexpr long MB_T = MB_V + 8L * 32 * 256;   // [panel 8][column 32][row 32]
+constexpr long MB_D = MB_T + 8L * 32 * 32;    // [256] diag R
+constexpr long MB_N = MB_D + 256;           // [256] squared column norms of the input
+constexpr long MB_X = MB_N + 256;           // [8] XCC id of each part
+constexpr long MB_GRANULES = MB_X + 8;
+
+#define QB_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+template <bool LOCAL>
+__device__ __forceinline__ void g_put(qword *g, double v, unsigned tag)
+{
+    const qword bits = (qword)__double_as_longlong(v);
+    const qword lo = (bits & 0xffffffffull) | ((qword)tag << 32), hi = (bits >> 32) | ((qword)tag << 32);
+    if (LOCAL) {
+        __hip_atomic_store(g, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(g + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+        __hip_atomic_store(g, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(g + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__device__ __forceinline__ void g_put_sel(qword *g, double v, unsigned tag, bool local)
+{
+    if (local) g_put<true>(g, v, tag);
+    else g_put<false>(g, v, tag);
+}
+__device__ __forceinline__ bool g_try(const qword *g, unsigned tag, double &v)
+{
+    const qword a = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const qword b = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v = __longlong_as_double((long long)((a & 0xffffffffull) | (b << 32)));
+    return (unsigned)(a >> 32) == tag && (unsigned)(b >> 32) == tag;
+}
+// bounded wait for one granule
+__device__ __forceinline__ double g_wait(const qword *g, unsigned tag, volatile int *s_abort)
+{
+    double v = 0.0;
+    for (unsigned s = 0; s < QB_SPIN; ++s) {
+        if (g_try(g, tag, v)) return v;
+        if ((s & 63u) == 63u && *s_abort) return 0.0;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    *s_abort = 1;
+    return 0.0;
+}
+// NJ granules at a fixed stride, all requests in flight at once; repeated until every tag is right
+template <int NJ>
+__device__ __forceinline__ void g_batch(const qword *base, long stride_q, unsigned tag, double (&v)[NJ], volatile int *s_abort)
+{
+    for (unsigned s = 0; s < QB_SPIN; ++s) {
+        qword a[NJ], b[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            a[j] = __hip_atomic_load(base + j * stride_q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            b[j] = __hip_atomic_load(base + j * stride_q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            ok = ok & ((unsigned)(a[j] >> 32) == tag) & ((unsigned)(b[j] >> 32) == tag);
+            v[j] = __longlong_as_double((long long)((a[j] & 0xffffffffull) | (b[j] << 32)));
+        }
+        if (ok) return;
+        if ((s & 63u) == 63u && *s_abort) return;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    *s_abort = 1;
+}
+
+template <int CTRL>
+__device__ __forceinline__ double qdpp(double x)
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// sum over the 8 lanes {8g .. 8g+7}; every lane receives the total
+__device__ __forceinline__ double qsum8(double x)
+{
+    x += qdpp<0xB1>(x);   // quad_perm [1,0,3,2]
+    x += qdpp<0x4E>(x);   // quad_perm [2,3,0,1]
+    x += qdpp<0x141>(x);  // row_half_mirror
+    return x;
+}
+__device__ __forceinline__ double qreadlane(double x, int l)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
+}
+// sqrt(x) and 1/sqrt(x) together (coupled Goldschmidt iterations from v_rsq_f64, then one correction of the root)
+__device__ __forceinline__ void q_sqrt_rsqrt(double x, double &root, double &rroot)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    const double d = __builtin_fma(-g, g, x);
+    root = __builtin_fma(d, h, g);
+    rroot = h + h;
+}
+__device__ __forceinline__ double q_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-x, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+
+#if defined(QRB_X_DUMP) || defined(QRB_X_DUMP2)
+__device__ double qrb_dump[256 * 32];
+#endif
+struct QbLds {
+    double *Vs;      // [32][VLD] staged panel V_p (column-major, natural rows); also the layout-conversion buffer
+    double *Ts;      // [32][TLD] T_p, column-major
+    double *Wx;      // [4 waves][16][64] partial W = V'[C Z] of each wave, met by its row-half partner
+    double *ub;      // [2][8][UST] the step's unscaled reflector u = xi v, sliced by row group
+    double *scal;    // [2][2] {1/xi, tau/xi} of the step
+    double *dotbuf;  // [2][32] u_j' x_c of every panel column c
+    double *Th;      // [32][UST] T-hat = T diag(1/xi) of my panel, row-major
+    double *rcps;    // [32] 1/xi, [32] tau, [32] nu of my panel's steps
+    double *dinv;    // [256] 1/D of the rows whose panel has been seen
+    double *dval;    // [32] D of my panel
+    double *nrm;     // [256] input column norms
+    int *ord;        // [256] position -> original column
+    int *xcc;        // [8]
+    volatile int *s_abort;
+};
+
+// ---- panel p from the mailbox into LDS: one poll on the granule its owner publishes last, then everything in one batch ----
+template <int P>
+__device__ __forceinline__ void qrb_fetch(const qword *mb, unsigned tag, const QbLds &L, int tid)
+{
+#ifdef QRB_X_NOFETCH
+    QB_BARRIER();
+    return;
+#endif
+#ifdef QRB_X_DELAY
+    for (int q = 0; q < 400; ++q) __builtin_amdgcn_s_sleep(127);
+#endif
+    const int r = tid;
+    // uniform column bases + one 32-bit lane offset: the 64 requests of a pass then share ONE address register (their
+    // column offsets do not fit the instruction's immediate, and 64 address pairs cost 128 registers)
+    const qword *vb = mb + 2 * (MB_V + ((long)P * 32) * 256);
+    const unsigned ro = 2u * (unsigned)r;
+    const qword *tb = mb + 2 * (MB_T + ((long)P * 32) * 32);
+    const qword *tmine = tb + 2L * ((tid >> 3) * 32 + 4 * (tid & 7));
+    const qword *dmine = mb + 2 * (MB_D + 32 * P + (tid & 31));
+    (void)g_wait(tb + 2L * (31 * 32 + 31), tag, L.s_abort);
+    for (unsigned s = 0; s < QB_SPIN; ++s) {
+        bool ok = true;
+        // (values go to LDS as they come; a pass with a stale granule is simply repeated)
+        if (r >= 32 * P) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                qword a[16], b[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const qword *cb = vb + 2L * (16 * half + j) * 256;
+                    a[j] = __hip_atomic_load(cb + ro, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    b[j] = __hip_atomic_load(cb + ro + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    ok = ok & ((unsigned)(a[j] >> 32) == tag) & ((unsigned)(b[j] >> 32) == tag);
+                    L.Vs[(16 * half + j) * VLD + r] = __longlong_as_double((long long)((a[j] & 0xffffffffull) | (b[j] << 32)));
+                }
+            }
+        }
+        {
+            qword a[5], b[5];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a[j] = __hip_atomic_load(tmine + 2 * j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                b[j] = __hip_atomic_load(tmine + 2 * j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            a[4] = __hip_atomic_load(dmine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            b[4] = __hip_atomic_load(dmine + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int j = 0; j < 5; ++j) ok = ok & ((unsigned)(a[j] >> 32) == tag) & ((unsigned)(b[j] >> 32) == tag);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                L.Ts[(tid >> 3) * TLD + 4 * (tid & 7) + j] = __longlong_as_double((long long)((a[j] & 0xffffffffull) | (b[j] << 32)));
+            if (tid < 32)
+                L.dinv[32 * P + tid] = 1.0 / fabs(__longlong_as_double((long long)((a[4] & 0xffffffffull) | (b[4] << 32))));
+        }
+        if (ok) break;
+        if (((s & 63u) == 63u && *L.s_abort) || s + 1 == QB_SPIN) {
+            *L.s_abort = 1;
+            break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+    QB_BARRIER();
+}
+
+// ---- [C Z] <- (I - V_p T_p' V_p') [C Z] on the row tiles t >= 2P ---------------------------------------------------
+template <int P, bool DO_C, bool DO_Z>
+__device__ __forceinline__ void qrb_apply(d4 (&c)[8], d4 (&z)[8], const QbLds &L, int wv, int lane)
+{
+#ifdef QRB_X_NOAPPLY
+    return;
+#endif
+    const int nn = lane & 15, kq = lane >> 4, rh = wv >> 1;
+    d4 wc[2], wz[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        wc[a] = (d4){0.0, 0.0, 0.0, 0.0};
+        wz[a] = (d4){0.0, 0.0, 0.0, 0.0};
+    }
+    // W = V' [C Z], my row tiles only
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const double *va = L.Vs + (16 * a + nn) * VLD + kq;
+#pragma unroll
+        for (int u = P; u < 8; ++u) {
+            const int t = 2 * u + rh;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double av = va[16 * t + 4 * r];
+                if (DO_C) wc[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, c[u][r], wc[a], 0, 0, 0);
+                if (DO_Z) wz[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, z[u][r], wz[a], 0, 0, 0);
+            }
+        }
+    }
+    // the two row halves of a column tile meet
+    {
+        double *mine = L.Wx + (wv * 16) * 64 + lane;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (DO_C) mine[(a * 4 + r) * 64] = wc[a][r];
+                if (DO_Z) mine[(8 + a * 4 + r) * 64] = wz[a][r];
+            }
+        QB_BARRIER();
+        const double *other = L.Wx + ((wv ^ 2) * 16) * 64 + lane;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (DO_C) wc[a][r] += other[(a * 4 + r) * 64];
+                if (DO_Z) wz[a][r] += other[(8 + a * 4 + r) * 64];
+            }
+    }
+    // Y = -T' W (T upper triangular: block (a, a') only for a <= a')
+    d4 yc[2], yz[2];
+#pragma unroll
+    for (int ap = 0; ap < 2; ++ap) {
+        yc[ap] = (d4){0.0, 0.0, 0.0, 0.0};
+        yz[ap] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int a = 0; a <= ap; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double tv = -L.Ts[(16 * ap + nn) * TLD + 16 * a + 4 * r + kq];
+                if (DO_C) yc[ap] = __builtin_amdgcn_mfma_f64_16x16x4f64(tv, wc[a][r], yc[ap], 0, 0, 0);
+                if (DO_Z) yz[ap] = __builtin_amdgcn_mfma_f64_16x16x4f64(tv, wz[a][r], yz[ap], 0, 0, 0);
+            }
+    }
+    // [C Z] += V Y
+#pragma unroll
+    for (int u = P; u < 8; ++u) {
+        const int t = 2 * u + rh;
+#pragma unroll
+        for (int ap = 0; ap < 2; ++ap)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double av = L.Vs[(16 * ap + 4 * r + kq) * VLD + 16 * t + nn];
+                if (DO_C) c[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, yc[ap][r], c[u], 0, 0, 0);
+                if (DO_Z) z[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, yz[ap][r], z[u], 0, 0, 0);
+            }
+    }
+    QB_BARRIER();  // Vs, Ts, Wx are free again
+}
+
+// column jj of the panel's compact-WY triangle (dlarft, forward / columnwise): T[0:jj, jj] = -tau T[0:jj, 0:jj] V[:, 0:jj]' v_jj.
+// dots[k] = u_k' u_jj for the finished columns k < jj; T-hat = T diag(1/xi) stays in LDS.  One wave, lanes 0..31 = rows.
+template <int W>
+__device__ __forceinline__ void qrb_tcolumn(const QbLds &L, qword *mb, unsigned tag, bool local, int lane, int jj)
+{
+    if (lane < 32) {
+        const double *dots = L.dotbuf + (jj & 1) * 32;
+        const double *th = L.Th + lane * UST;
+        double acc = 0.0;
+        for (int k = 0; k < jj; k += 2) {
+            const double2 dd = *reinterpret_cast<const double2 *>(dots + k);
+            const double2 tt = *reinterpret_cast<const double2 *>(th + k);
+            acc = __builtin_fma(tt.x, dd.x, acc);
+            acc = __builtin_fma(tt.y, k + 1 < jj ? dd.y : 0.0, acc);
+        }
+        const double tau = L.rcps[32 + jj], rcp = L.rcps[jj];
+        const double t = lane < jj ? -(tau * rcp) * acc : (lane == jj ? tau : 0.0);
+        L.Th[lane * UST + jj] = t * rcp;
+        if (*L.s_abort != 2) g_put_sel(mb + 2 * (MB_T + ((long)W * 32 + jj) * 32 + lane), t, tag, local);
+    }
+}
+
+// ---- panel W factored by its owner -------------------------------------------------------------------------------
+// thread (pc = tid >> 3, rg = tid & 7) holds column pc of the panel, rows 16 (k >> 1) + 2 rg + (k & 1), k = 0..31 (rows below
+// 32 W carry finished R entries).  Step j: the owner's 8 lanes give the norm and the reflector scalars (UDT.jl:133-148) and
+// leave the UNSCALED reflector u = xi v in LDS; after ONE barrier every column takes its dot product with u and is updated
+// (finished columns with coefficient 0: their dot products are V' v_j, the raw material of T).  While the NEXT owner wave
+// works on its norm and scalars, two other waves publish v_j = u / xi with diag R, and column j - 1 of T.
+template <int W>
+__device__ __forceinline__ void qrb_own(d4 (&c)[8], const QbLds &L, qword *mb, unsigned tag, bool local, int tid,
+                                        double *__restrict__ Tout, int apply_pivot, int force_timeout, int part)
+{
+#ifdef QRB_X_NOOWN
+    return;
+#endif
+    constexpr int KB0 = 4 * W;
+    constexpr int NI = (256 - 32 * W + 63) / 64;
+    const int wv = tid >> 6, lane = tid & 63;
+    // accumulator layout -> panel layout through the (free) panel buffer
+#ifdef QRB_X_NOPS
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+#endif
+    {
+        const int nn = lane & 15, kq = lane >> 4, ct = wv & 1, rh = wv >> 1;
+        double *cs = L.Vs + (16 * ct + nn) * VLD + kq;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cs[16 * (2 * u + rh) + 4 * r] = c[u][r];
+    }
+    if (tid < 32) {
+#pragma unroll
+        for (int k = 0; k < UST; ++k) L.Th[tid * UST + k] = 0.0;
+    }
+    QB_BARRIER();
+    const int pc = tid >> 3, rg = tid & 7;
+    double x[32];
+    {
+        const double2 *cs = reinterpret_cast<const double2 *>(L.Vs + pc * VLD + 2 * rg);
+#pragma unroll
+        for (int k = 0; k < 32; k += 2) {
+            const double2 a = cs[4 * k];  // 16 (k >> 1) doubles further
+            x[k] = a.x;
+            x[k + 1] = a.y;
+        }
+    }
+    for (int j = 0; j < 32; ++j) {
+        const int par = j & 1, g = 32 * W + j;
+        if (force_timeout >= 2 && part == 3 && j == ((force_timeout - 2) & 31)) {
+            // test hook: this part stops publishing, as a workgroup that lost its CU would
+            if (tid == 0) *L.s_abort = 2;
+        }
+        if (wv == (j >> 3)) {
+            double n0 = 0.0, n1 = 0.0, xg = 0.0;
+#pragma unroll
+            for (int k = KB0; k < 32; k += 2) {
+                if (k < KB0 + 4) {
+                    const int ra = 32 * W + 16 * ((k - KB0) >> 1) + 2 * rg;
+                    n0 += (ra >= g ? 1.0 : 0.0) * (x[k] * x[k]);
+                    n1 += (ra + 1 >= g ? 1.0 : 0.0) * (x[k + 1] * x[k + 1]);
+                    xg += (ra == g ? x[k] : 0.0) + (ra + 1 == g ? x[k + 1] : 0.0);
+                } else {
+                    n0 = __builtin_fma(x[k], x[k], n0);
+                    n1 = __builtin_fma(x[k + 1], x[k + 1], n1);
+                }
+            }
+            const int ol = 8 * (j & 7);
+            const double maxval = qreadlane(qsum8(n0 + n1), ol), xi1 = qreadlane(qsum8(xg), ol);
+            // UDT.jl:133-148, branch-free (a zero column keeps tau = 0 and stays as it is)
+            const bool nz = maxval != 0.0;
+            double rootn, rrootn;
+            q_sqrt_rsqrt(nz ? maxval : 1.0, rootn, rrootn);
+            const double nu = nz ? copysign(rootn, xi1) : -xi1;
+            const double xi = nz ? xi1 + nu : 1.0;
+            const double tj = nz ? __builtin_fma(fabs(xi1), rrootn, 1.0) : 0.0;  // xi / nu
+            const double rcp = q_rcp(xi), trr = tj * rcp;
+            if ((lane >> 3) == (j & 7)) {
+                double2 *dst = reinterpret_cast<double2 *>(L.ub + (par * 8 + rg) * UST);
+#pragma unroll
+                for (int k = KB0; k < 32; k += 2) {
+                    double a = x[k], b = x[k + 1];
+                    if (k < KB0 + 4) {
+                        const int ra = 32 * W + 16 * ((k - KB0) >> 1) + 2 * rg;
+                        a = ra > g ? a : (ra == g ? xi : 0.0);
+                        b = ra + 1 > g ? b : (ra + 1 == g ? xi : 0.0);
+                        x[k] = ra == g ? -nu : x[k];
+                        x[k + 1] = ra + 1 == g ? -nu : x[k + 1];
+                    }
+                    dst[k >> 1] = make_double2(a, b);
+                }
+                if (rg == 0) {
+                    *reinterpret_cast<double2 *>(L.scal + par * 2) = make_double2(rcp, trr);
+                    L.rcps[j] = rcp;
+                    L.rcps[32 + j] = tj;
+                    L.rcps[64 + j] = nu;
+                }
+            }
+        }
+        QB_BARRIER();
+        {
+            const double2 sc = *reinterpret_cast<const double2 *>(L.scal + par * 2);
+            const double2 *uq = reinterpret_cast<const double2 *>(L.ub + (par * 8 + rg) * UST);
+            double2 uu[16];
+            double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+            for (int k = KB0; k < 32; k += 2) {
+                uu[k >> 1] = uq[k >> 1];
+                d0 = __builtin_fma(uu[k >> 1].x, x[k], d0);
+                d1 = __builtin_fma(uu[k >> 1].y, x[k + 1], d1);
+            }
+            const double dot = qsum8(d0 + d1);
+            if (rg == 0) L.dotbuf[par * 32 + pc] = dot;
+            const double coef = pc > j ? (dot * sc.x) * sc.y : 0.0;
+#pragma unroll
+            for (int k = KB0; k < 32; k += 2) {
+                x[k] = __builtin_fma(-uu[k >> 1].x, coef, x[k]);
+                x[k + 1] = __builtin_fma(-uu[k >> 1].y, coef, x[k + 1]);
+            }
+        }
+        // in the shadow of the next owner's norm and scalars
+        const int on = ((j + 1) >> 3) & 3;
+        if (wv == ((on + 1) & 3)) {  // v_j = u / xi and diag R, to the mailbox
+            const double rcp = L.rcps[j];
+            const bool quiet = *L.s_abort == 2;  // forced time-out: nothing is published any more
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int row = 32 * W + lane + 64 * i;
+                if (row < 256) {
+                    const double u = L.ub[(par * 8 + ((row & 15) >> 1)) * UST + 2 * (row >> 4) + (row & 1)];
+                    const double v = row > g ? u * rcp : (row == g ? 1.0 : 0.0);
+                    if (!quiet) g_put_sel(mb + 2 * (MB_V + ((long)W * 32 + j) * 256 + row), v, tag, local);
+                }
+            }
+            if (lane == 0) {
+                const double nu = L.rcps[64 + j];
+                L.dval[j] = fabs(nu);
+                L.dinv[g] = 1.0 / fabs(nu);
+                if (!quiet) g_put_sel(mb + 2 * (MB_D + g), -nu, tag, local);
+            }
+        } else if (wv == ((on + 2) & 3) && j >= 1) {
+            qrb_tcolumn<W>(L, mb, tag, local, lane, j - 1);
+        }
+    }
+    QB_BARRIER();
+    if (wv == 0) qrb_tcolumn<W>(L, mb, tag, local, lane, 31);
+#ifdef QRB_X_DUMP2
+    if (W == 1) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            qrb_dump[tid * 4 + k] = x[k];
+            qrb_dump[1024 + tid * 4 + k] = L.dinv[16 * (k >> 1) + 2 * rg + (k & 1)];
+        }
+    }
+#endif
+    // T = D^-1 R of my column: rows <= its position (UDT.jl:283-306), zeros below
+    {
+        const int gc = 32 * W + pc;  // position of my column
+        const int dc = apply_pivot ? L.ord[gc] : gc;
+        double2 *tcol = reinterpret_cast<double2 *>(Tout + (long)256 * dc + 2 * rg);
+#pragma unroll
+        for (int k = 0; k < 32; k += 2) {
+            const int ra = 16 * (k >> 1) + 2 * rg;
+            double a = 0.0, b = 0.0;
+            if (k < KB0 + 4) {
+                const double2 di = *reinterpret_cast<const double2 *>(L.dinv + ra);
+                a = ra <= gc ? x[k] * di.x : 0.0;
+                b = ra + 1 <= gc ? x[k + 1] * di.y : 0.0;
+            }
+            tcol[4 * k] = make_double2(a, b);
+        }
+    }
+}
+
+// the program of part W: panels in order, my own panel in between.  (W is a template constant so that the compiler sees
+// what is live where: my columns C are dead once my panel is factored, and Z alone goes through the later panels.)
+template <int W, int P>
+__device__ __forceinline__ void qrb_panel(d4 (&c)[8], d4 (&z)[8], const QbLds &L, qword *mb, unsigned tag, bool local, int tid,
+                                          double *__restrict__ Tout, int apply_pivot, int force_timeout)
+{
+    const int wv = tid >> 6, lane = tid & 63;
+    if (P == W) {
+        qrb_own<P>(c, L, mb, tag, local, tid, Tout, apply_pivot, force_timeout, W);
+        QB_BARRIER();
+        if (P > 0) {  // the update of Z that made way for my panel
+            qrb_fetch<(P > 0 ? P - 1 : 0)>(mb, tag, L, tid);
+            qrb_apply<(P > 0 ? P - 1 : 0), false, true>(c, z, L, wv, lane);
+        }
+    }
+    if (P >= W) {
+        qrb_fetch<P>(mb, tag, L, tid);
+        qrb_apply<P, false, true>(c, z, L, wv, lane);
+    } else if (P == W - 1) {
+        qrb_fetch<P>(mb, tag, L, tid);
+        qrb_apply<P, true, false>(c, z, L, wv, lane);
+#ifdef QRB_X_DUMP
+        if (W == 1) {
+            const int nn = lane & 15, kq = lane >> 4, ct = wv & 1, rh = wv >> 1;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) qrb_dump[(16 * (2 * u + rh) + 4 * r + kq) + 256 * (16 * ct + nn)] = c[u][r];
+        }
+#endif
+    } else {
+        qrb_fetch<P>(mb, tag, L, tid);
+        qrb_apply<P, true, true>(c, z, L, wv, lane);
+    }
+}
+template <int W>
+__device__ __forceinline__ void qrb_part(d4 (&c)[8], d4 (&z)[8], const QbLds &L, qword *mb, unsigned tag, bool local, int tid,
+                                         double *__restrict__ Tout, int apply_pivot, int force_timeout)
+{
+    qrb_panel<W, 0>(c, z, L, mb, tag, local, tid, Tout, apply_pivot, force_timeout);
+    qrb_panel<W, 1>(c, z, L, mb, tag, local, tid, Tout, apply_pivot, force_timeout);
+    qrb_panel<W, 2>(c, z, L, mb, tag, local, tid, Tout, apply_pivot, force_timeout);
+    qrb_panel<W, 3>(c, z, L, mb, tag, local, tid, Tout, apply_pivot, force_timeout);
+    qrb_panel<W, 4>(c, z, L, mb, tag, local, tid, Tout, apply_pivot, force_timeout);
+    qrb_panel<W, 5>(c, z, L, mb, tag, local, tid, Tout, apply_pivot, force_timeout);
+    qrb_panel<W, 6>(c, z, L, mb, tag, local, tid, Tout, apply_pivot, force_timeout);
+    qrb_panel<W, 7>(c, z, L, mb, tag, local, tid, Tout, apply_pivot, force_timeout);
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(QB_THREADS) void qrb_udt_kernel(int n_units, const double *__restrict__ Aall, long strideA,
+                                                            double *__restrict__ Uall, long strideU,
+                                                            double *__restrict__ Dall, long strideD,
+                                                            double *__restrict__ Tall, long strideT,
+                                                            int *__restrict__ pivall, qword *mailbox, unsigned tag,
+                                                            int *errflag, int apply_pivot, int force_sc1, int force_timeout)
+{
+    extern __shared__ __attribute__((aligned(16))) double qb_lds[];
+    QbLds L;
+    {
+        double *p = qb_lds;
+        L.Vs = p; p += 32 * VLD;
+        L.Ts = p; p += 32 * TLD;
+        L.Wx = p; p += 4 * 16 * 64;
+        L.ub = p; p += 2 * 8 * UST;
+        L.scal = p; p += 4;
+        L.dotbuf = p; p += 64;
+        L.Th = p; p += 32 * UST;
+        L.rcps = p; p += 96;
+        L.dinv = p; p += 256;
+        L.dval = p; p += 32;
+        L.nrm = p; p += 256;
+        int *q = reinterpret_cast<int *>(p);
+        L.ord = q; q += 256;
+        L.xcc = q; q += 8;
+        L.s_abort = q;
+    }
+    const int bid = blockIdx.x, xcd = bid & 7, seq = bid >> 3;
+    const int unit = (seq / 8) * 8 + xcd, part = seq % 8;
+    if (unit >= n_units) return;  // all parts of a missing unit leave together
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    const double *__restrict__ A = Aall + (long)unit * strideA;
+    qword *mb = mailbox + (long)unit * MB_GRANULES * 2;
+    if (tid == 0) *L.s_abort = 0;
+    if (force_timeout == 1) {  // test hook: a launch whose hand-offs all time out at once
+        if (tid == 0) atomicOr(errflag, 16);
+        return;
+    }
+    __syncthreads();
+
+    // ---- column norms of the input: my 32 original columns, then everybody's through the mailbox ----
+    {
+        const int cc = tid >> 3, rg = tid & 7, col = 32 * part + cc;
+        const double2 *ap = reinterpret_cast<const double2 *>(A + (long)col * 256) + rg;
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const double2 a = ap[8 * q];
+            s0 = __builtin_fma(a.x, a.x, s0);
+            s1 = __builtin_fma(a.y, a.y, s1);
+        }
+        const double nrm = qsum8(s0 + s1);
+        if (rg == 0) g_put<false>(mb + 2 * (MB_N + col), nrm, tag);
+    }
+    if (tid == 0) {
+        const unsigned my_xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 0xfu;  // HW_REG_XCC_ID[3:0]
+        g_put<false>(mb + 2 * (MB_X + part), (double)my_xcc, tag);
+    }
+    L.nrm[tid] = g_wait(mb + 2 * (MB_N + tid), tag, L.s_abort);
+    L.ord[tid] = tid;
+    if (tid < 8) L.xcc[tid] = (int)g_wait(mb + 2 * (MB_X + tid), tag, L.s_abort);
+    __syncthreads();
+    bool local = force_sc1 == 0;
+#pragma unroll
+    for (int q = 1; q < 8; ++q) local = local && L.xcc[q] == L.xcc[0];
+    // ---- position of every column: descending norm, first maximum first (UDT.jl:151-168 for the first step) ----
+    {
+        const double my = L.nrm[tid];
+        int rank = 0;
+        const double2 *np2 = reinterpret_cast<const double2 *>(L.nrm);
+        for (int k = 0; k < 256; k += 2) {
+            const double2 o = np2[k >> 1];
+            rank += (o.x > my) | ((o.x == my) & (k < tid));
+            rank += (o.y > my) | ((o.y == my) & (k + 1 < tid));
+        }
+        L.ord[rank & 255] = tid;  // (ranks are a permutation unless a norm is NaN; ord starts as the identity)
+    }
+    __syncthreads();
+    if (part == 0) pivall[(long)unit * 256 + tid] = L.ord[tid];
+
+    // ---- my 32 columns (positions 32 part ..) in accumulator layout; Z = my columns of the identity ----
+    d4 c[8], z[8];
+    {
+        const int nn = lane & 15, kq = lane >> 4, ct = wv & 1, rh = wv >> 1;
+        const int pos = 32 * part + 16 * ct + nn;
+        const double *ac = A + (long)L.ord[pos] * 256 + kq;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * (2 * u + rh) + 4 * r + kq;
+                c[u][r] = ac[row - kq];
+                z[u][r] = row == pos ? 1.0 : 0.0;
+            }
+    }
+    double *__restrict__ Tout = Tall + (long)unit * strideT;
+    switch (part) {
+    case 0: qrb_part<0>(c, z, L, mb, tag, local, tid, Tout, apply_pivot, force_timeout); break;
+    case 1: qrb_part<1>(c, z, L, mb, tag, local, tid, Tout, apply_pivot, force_timeout); break;
+    case 2: qrb_part<2>(c, z, L, mb, tag, local, tid, Tout, apply_pivot, force_timeout); break;
+    case 3: qrb_part<3>(c, z, L, mb, tag, local, tid, Tout, apply_pivot, force_timeout); break;
+    case 4: qrb_part<4>(c, z, L, mb, tag, local, tid, Tout, apply_pivot, force_timeout); break;
+    case 5: qrb_part<5>(c, z, L, mb, tag, local, tid, Tout, apply_pivot, force_timeout); break;
+    case 6: qrb_part<6>(c, z, L, mb, tag, local, tid, Tout, apply_pivot, force_timeout); break;
+    default: qrb_part<7>(c, z, L, mb, tag, local, tid, Tout, apply_pivot, force_timeout); break;
+    }
+
+    // ---- U = Q: Z holds columns 32 part .. of Q', i.e. rows 32 part .. of Q ----
+    {
+        const int nn = lane & 15, kq = lane >> 4, ct = wv & 1, rh = wv >> 1;
+        double *uo = Uall + (long)unit * strideU + 32 * part + 16 * ct + nn;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) uo[(long)256 * (16 * (2 * u + rh) + 4 * r + kq)] = z[u][r];
+    }
+    if (tid < 32) Dall[(long)unit * strideD + 32 * part + tid] = L.dval[tid];
+    if (tid == 0 && *L.s_abort) atomicOr(errflag, 16);
+}
+
+#if defined(QRB_X_DUMP) || defined(QRB_X_DUMP2)
+extern "C" int dqmc_debug_qrb_dump(double *host)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(qrb_dump), sizeof(double) * 256 * 32);
+}
+#endif
+size_t qrb_lds_bytes()
+{
+    return (size_t)(32 * VLD + 32 * TLD + 4 * 16 * 64 + 2 * 8 * UST + 4 + 64 + 32 * UST + 96 + 256 + 32 + 256) * sizeof(double) +
+           (256 + 8 + 4) * sizeof(int);
+}
+size_t qrb_mailbox_bytes(int n_units) { return (size_t)((n_units + 7) / 8) * 8 * MB_GRANULES * 16; }
+
+// workgroups of the kernel that one CU holds (its LDS admits one)
+int qrb_blocks_per_cu()
+{
+    static int cached = -1;
+    if (cached >= 0) return cached;
+    (void)hipFuncSetAttribute((const void *)qrb_udt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)qrb_lds_bytes());
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, qrb_udt_kernel, QB_THREADS, qrb_lds_bytes()) != hipSuccess) nb = 0;
+    cached = nb;
+    return nb;
+}
+
+hipError_t launch_udt_blocked(int n_units, const double *A, long strideA, double *U, long strideU, double *D, long strideD,
+                              double *T, long strideT, int *pivot, QrCoopWorkspace *ws, int apply_pivot, hipStream_t s)
+{
+    if (!ws || !ws->mailbox2) return hipErrorInvalidValue;
+    const int blocks = ((n_units + 7) / 8) * 64;
+    if (blocks > ws->blk_max_blocks) return hipErrorInvalidValue;
+    ws->epoch += 1;
+    const unsigned tag = (unsigned)(ws->epoch & 0xffffffffull);
+    hipLaunchKernelGGL(qrb_udt_kernel, dim3(blocks), dim3(QB_THREADS), qrb_lds_bytes(), s, n_units, A, strideA, U, strideU, D,
+                       strideD, T, strideT, pivot, reinterpret_cast<qword *>(ws->mailbox2), tag, ws->errflag, apply_pivot,
+                       ws->force_sc1, ws->force_timeout);
+    return hipGetLastError();
+}
+
+}  // namespace dqmc

@@ -274,15 +274,65 @@ static void reflector_apply(int n, double *A, int j, double tau)
     }
 }
 
+/* STUDY SWITCH, not the reference's rule (default 0 = the reference's rule, UDT.jl:212-246).
+ * Bit s set: the factorisation at call site s (0 = add_slice_sequence_left/right and every other
+ * caller, 1 = first UDT of calculate_greens_AVX!, 2 = second one) takes its pivot order ONCE, from
+ * the column norms of the input (stable descending sort, first maximum first), and then runs the
+ * same Householder steps without a search - the device's pre-pivoted blocked factorisation in
+ * exact-arithmetic terms.  Used by tests to compare the device's factors U, D, T one by one and to
+ * measure how far G moves; parity itself is always asserted against mode 0. */
+static int orc_udt_presort_mask = 0;
+static int orc_udt_site = 0;
+static int orc_udt_local_mask = 0; /* with presort: pivot search restricted to the 32-column panel */
+void orc_set_udt_presort(int mask) { orc_udt_presort_mask = mask & 7; orc_udt_local_mask = (mask >> 3) & 7; }
+
+static void presort_columns(int n, double *input, int64_t *pivot, double *temp)
+{
+    double *nrm = (double *)malloc(sizeof(double) * n);
+    int *ord = (int *)malloc(sizeof(int) * n);
+    double *cp = (double *)malloc(sizeof(double) * (size_t)n * n);
+    for (int c = 0; c < n; ++c) {
+        double m = 0.0;
+        for (int k = 0; k < n; ++k) m += input[k + (size_t)n * c] * input[k + (size_t)n * c];
+        nrm[c] = m;
+        ord[c] = c;
+    }
+    for (int i = 1; i < n; ++i) { /* stable insertion sort, descending */
+        int o = ord[i];
+        int k = i - 1;
+        while (k >= 0 && nrm[ord[k]] < nrm[o]) { ord[k + 1] = ord[k]; --k; }
+        ord[k + 1] = o;
+    }
+    memcpy(cp, input, sizeof(double) * (size_t)n * n);
+    for (int j = 0; j < n; ++j) {
+        memcpy(input + (size_t)n * j, cp + (size_t)n * ord[j], sizeof(double) * n);
+        pivot[j] = ord[j] + 1;
+    }
+    (void)temp;
+    free(nrm); free(ord); free(cp);
+}
+
 /* UDT.jl:192-306 */
 void orc_udt_pivot(int n, double *U, double *D, double *input, int64_t *pivot,
                    double *temp, int apply_pivot)
 {
     for (int i = 0; i < n; ++i) pivot[i] = i + 1;
+    const int presort = (orc_udt_presort_mask >> orc_udt_site) & 1;
+    if (presort) presort_columns(n, input, pivot, temp);
 
     for (int j = 0; j < n; ++j) {
-        double maxval;
-        int jm = indmaxcolumn(n, input, j, &maxval);
+        double maxval = 0.0;
+        int jm = presort ? j : indmaxcolumn(n, input, j, &maxval);
+        if (presort) { /* no search (or a search inside the 32-column panel only) */
+            const int jend = ((orc_udt_local_mask >> orc_udt_site) & 1) ? ((j / 32) * 32 + 32 < n ? (j / 32) * 32 + 32 : n) : j + 1;
+            jm = j;
+            maxval = -1.0;
+            for (int c = j; c < jend; ++c) {
+                double mi = 0.0;
+                for (int k = j; k < n; ++k) mi += input[k + (size_t)n * c] * input[k + (size_t)n * c];
+                if (mi > maxval) { maxval = mi; jm = c; }
+            }
+        }
         if (jm != j) {
             int64_t tp = pivot[jm];
             pivot[jm] = pivot[j];
@@ -341,12 +391,16 @@ void orc_calculate_greens(int n, double *Ul, double *Dl, double *Tl, double *Ur,
     orc_vmul_nt(n, G, Tl, Tr);                       /* :346 */
     orc_vmul_nd(n, Tr, G, Dr);                       /* :347 */
     orc_vmul_dn(n, G, Dl, Tr);                       /* :348 */
+    orc_udt_site = 1;
     orc_udt_pivot(n, Tr, Dr, G, pivot, temp, 0);     /* :349 */
+    orc_udt_site = 0;
     orc_vmul_nn(n, Tl, Ul, Tr);                      /* :360 */
     orc_rdivp(n, Ur, G, Ul, pivot);                  /* :361 */
     orc_vmul_tn(n, Tr, Tl, Ur);                      /* :362 */
     for (int i = 0; i < n; ++i) Tr[i + (size_t)n * i] += Dr[i]; /* :368 rvadd! */
+    orc_udt_site = 2;
     orc_udt_pivot(n, Ul, Dr, Tr, pivot, temp, 0);    /* :376 */
+    orc_udt_site = 0;
     orc_rdivp(n, Ur, Tr, G, pivot);                  /* :377 */
     orc_vmul_nn(n, Tr, Tl, Ul);                      /* :378 */
     for (int i = 0; i < n; ++i) Dl[i] = 1.0 / Dr[i]; /* :382-384 */

@@ -52,6 +52,8 @@ void orc_vmul_nd(int n, double *C, const double *A, const double *d); /* A * Dia
 void orc_vmul_dn(int n, double *C, const double *d, const double *B); /* Diagonal(d) * B */
 void orc_rdivp(int n, double *A, const double *T, double *O, const int64_t *pivot /* 1-based */);
 /* src/linalg/UDT.jl:192-306 ; pivot is 1-based on output */
+/* study switch (see dqmc_oracle.c): pre-sorted pivot order per call site; 0 = reference rule */
+void orc_set_udt_presort(int mask);
 void orc_udt_pivot(int n, double *U, double *D, double *T, int64_t *pivot,
                    double *temp, int apply_pivot);
 /* src/flavors/DQMC/stack.jl:337-393 ; overwrites all inputs */

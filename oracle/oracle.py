@@ -59,6 +59,8 @@ def lib(path=None):
                      "orc_sweep_spatial", "orc_update", "orc_prepare"):
             getattr(L, name).argtypes = [C.c_void_p]
             getattr(L, name).restype = None
+        L.orc_set_udt_presort.argtypes = [C.c_int]
+        L.orc_set_udt_presort.restype = None
         L.orc_sweeps.argtypes = [C.c_void_p, C.c_int]
         L.orc_sweeps.restype = None
         L.orc_update_until_measure.argtypes = [C.c_void_p]

@@ -41,9 +41,15 @@ def test_udt_contracts(gpu, O, n, apply_pivot):
     X = rng.standard_normal((4, n, n))
     X[1] *= np.exp(rng.uniform(-20, 20, size=n))[None, :]   # graded columns as in a DQMC chain
     U, D, T, piv = gpu.udt_AVX_pivot(X, apply_pivot)
+    # n = 256 takes the one-launch form whose pivot order is fixed up front (csrc/qrb.hip; tests/test_gpu_udt_blocked.py):
+    # D is then not sorted (the reference's contracts, test/slice_matrices.jl:202-234, do not ask for it) and the oracle to
+    # compare the factors with is the oracle run with the same pre-sorted order
+    presorted = n == 256
     for i in range(X.shape[0]):
         assert relerr(U[i].T @ U[i], np.eye(n)) < 1e-12
-        assert np.all(D[i] > 0) and np.all(np.diff(D[i]) <= 1e-12 * D[i][:-1])
+        assert np.all(D[i] > 0)
+        if not presorted:
+            assert np.all(np.diff(D[i]) <= 1e-12 * D[i][:-1])
         assert sorted(piv[i]) == list(range(1, n + 1))
         if apply_pivot:
             rec = (U[i] * D[i]) @ T[i]
@@ -53,7 +59,11 @@ def test_udt_contracts(gpu, O, n, apply_pivot):
         scale = np.abs(X[i]).max(axis=0)
         assert (np.abs(rec - X[i]) / scale[None, :]).max() < 1e-12
         # same decomposition as the oracle when no pivot tie flips
-        Uo, Do, To, po = O.udt_pivot(X[i], apply_pivot)
+        O.lib().orc_set_udt_presort(1 if presorted else 0)
+        try:
+            Uo, Do, To, po = O.udt_pivot(X[i], apply_pivot)
+        finally:
+            O.lib().orc_set_udt_presort(0)
         if np.array_equal(po, piv[i]):
             assert relerr(D[i], Do) < 1e-10
             assert relerr(U[i], Uo) < 1e-9
