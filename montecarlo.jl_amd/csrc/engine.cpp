@@ -335,7 +335,7 @@ static int alloc_qr_workspace(dqmc_handle *h)
     h->qr_ws.no_coop = getenv("DQMC_QR_NOCOOP") != nullptr;
     h->qr_ws.rows = getenv("DQMC_QR_ROWS") != nullptr && qr_rows_blocks_per_cu() >= 1;
     if (const char *e = getenv("DQMC_QR_FORCE_TIMEOUT"))
-        h->qr_ws.force_timeout = strncmp(e, "step:", 5) == 0 ? 2 + atoi(e + 5) : 1;
+        h->qr_ws.force_timeout = strncmp(e, "step:", 5) == 0 ? 2 + atoi(e + 5) : (strncmp(e, "extra:", 6) == 0 ? 1000 + atoi(e + 6) : 1);
     // pre-pivoted blocked UDT in one launch (qrb.hip): n == 256, all eight workgroups of every unit co-resident.
     // DQMC_QR_NOBLOCKED: off; DQMC_QRB_SITES: bit mask of the call sites that use it (1 = slice-sequence builds and every other
     // caller, 2 = first, 4 = second factorisation of calculate_greens_AVX!)

@@ -53,6 +53,10 @@ constexpr long MB_GRANULES = MB_X + 8;
 
 #define QB_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
+// the workgroup's abort word in LDS: relaxed atomic accesses (re-read every time, no waits attached)
+__device__ __forceinline__ int abort_get(int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void abort_set(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
 template <bool LOCAL>
 __device__ __forceinline__ void g_put(qword *g, double v, unsigned tag)
 {
@@ -79,20 +83,20 @@ __device__ __forceinline__ bool g_try(const qword *g, unsigned tag, double &v)
     return (unsigned)(a >> 32) == tag && (unsigned)(b >> 32) == tag;
 }
 // bounded wait for one granule
-__device__ __forceinline__ double g_wait(const qword *g, unsigned tag, volatile int *s_abort)
+__device__ __forceinline__ double g_wait(const qword *g, unsigned tag, int *s_abort)
 {
     double v = 0.0;
     for (unsigned s = 0; s < QB_SPIN; ++s) {
         if (g_try(g, tag, v)) return v;
-        if ((s & 63u) == 63u && *s_abort) return 0.0;
+        if ((s & 63u) == 63u && abort_get(s_abort)) return 0.0;
         __builtin_amdgcn_s_sleep(2);
     }
-    *s_abort = 1;
+    abort_set(s_abort, 1);
     return 0.0;
 }
 // NJ granules at a fixed stride, all requests in flight at once; repeated until every tag is right
 template <int NJ>
-__device__ __forceinline__ void g_batch(const qword *base, long stride_q, unsigned tag, double (&v)[NJ], volatile int *s_abort)
+__device__ __forceinline__ void g_batch(const qword *base, long stride_q, unsigned tag, double (&v)[NJ], int *s_abort)
 {
     for (unsigned s = 0; s < QB_SPIN; ++s) {
         qword a[NJ], b[NJ];
@@ -108,10 +112,10 @@ __device__ __forceinline__ void g_batch(const qword *base, long stride_q, unsign
             v[j] = __longlong_as_double((long long)((a[j] & 0xffffffffull) | (b[j] << 32)));
         }
         if (ok) return;
-        if ((s & 63u) == 63u && *s_abort) return;
+        if ((s & 63u) == 63u && abort_get(s_abort)) return;
         __builtin_amdgcn_s_sleep(2);
     }
-    *s_abort = 1;
+    abort_set(s_abort, 1);
 }
 
 template <int CTRL>
@@ -129,10 +133,6 @@ __device__ __forceinline__ double qsum8(double x)
     x += qdpp<0x4E>(x);   // quad_perm [2,3,0,1]
     x += qdpp<0x141>(x);  // row_half_mirror
     return x;
-}
-__device__ __forceinline__ double qreadlane(double x, int l)
-{
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
 }
 // sqrt(x) and 1/sqrt(x) together (coupled Goldschmidt iterations from v_rsq_f64, then one correction of the root)
 __device__ __forceinline__ void q_sqrt_rsqrt(double x, double &root, double &rroot)
@@ -158,6 +158,24 @@ __device__ __forceinline__ double q_rcp(double x)
     return __builtin_fma(r, e, r);
 }
 
+#ifdef QRB_STAMPS  // diagnostic build only (make stamps; tools/qrb_stamps.py): s_memtime of thread 0 of every part of unit 0
+__device__ long long *qrb_stamp_ptr = nullptr;  // [part 8][event 64]
+#define QRB_STAMP(ID)                                                                 \
+    do {                                                                              \
+        if (L.stamps && (threadIdx.x == 0)) L.stamps[ID] = (long long)__builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define QRB_STAMP(ID)
+#endif
+#ifdef QRB_FINE  // diagnostic: cycle stamps inside the steps of one part's panel (tools/qrb_fine.py)
+__device__ long long *qrb_fine_ptr = nullptr;  // [wave 4][step 32][point 8]
+#define QRB_FINE_PT(P)                                                                                   \
+    do {                                                                                                 \
+        if (W == QRB_FINE && lane == 0) L.fst[(wv * 32 + j) * 8 + (P)] = (long long)__builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define QRB_FINE_PT(P)
+#endif
 #if defined(QRB_X_DUMP) || defined(QRB_X_DUMP2)
 __device__ double qrb_dump[256 * 32];
 #endif
@@ -175,7 +193,9 @@ struct QbLds {
     double *nrm;     // [256] input column norms
     int *ord;        // [256] position -> original column
     int *xcc;        // [8]
-    volatile int *s_abort;
+    int *s_abort;  // (never volatile: a volatile access makes the compiler wait for every store in flight, vmcnt(0))
+    long long *stamps;  // diagnostic build: event times of this part (unit 0), else null
+    long long *fst;     // diagnostic build (QRB_FINE): [wave 4][step 32][point 8]
 };
 
 // ---- panel p from the mailbox into LDS: one poll on the granule its owner publishes last, then everything in one batch ----
@@ -197,7 +217,9 @@ __device__ __forceinline__ void qrb_fetch(const qword *mb, unsigned tag, const Q
     const qword *tb = mb + 2 * (MB_T + ((long)P * 32) * 32);
     const qword *tmine = tb + 2L * ((tid >> 3) * 32 + 4 * (tid & 7));
     const qword *dmine = mb + 2 * (MB_D + 32 * P + (tid & 31));
+    QRB_STAMP(8 + 4 * P + 0);
     (void)g_wait(tb + 2L * (31 * 32 + 31), tag, L.s_abort);
+    QRB_STAMP(8 + 4 * P + 1);
     for (unsigned s = 0; s < QB_SPIN; ++s) {
         bool ok = true;
         // (values go to LDS as they come; a pass with a stale granule is simply repeated)
@@ -236,13 +258,14 @@ __device__ __forceinline__ void qrb_fetch(const qword *mb, unsigned tag, const Q
                 L.dinv[32 * P + tid] = 1.0 / fabs(__longlong_as_double((long long)((a[4] & 0xffffffffull) | (b[4] << 32))));
         }
         if (ok) break;
-        if (((s & 63u) == 63u && *L.s_abort) || s + 1 == QB_SPIN) {
-            *L.s_abort = 1;
+        if (((s & 63u) == 63u && abort_get(L.s_abort)) || s + 1 == QB_SPIN) {
+            abort_set(L.s_abort, 1);
             break;
         }
         __builtin_amdgcn_s_sleep(2);
     }
     QB_BARRIER();
+    QRB_STAMP(8 + 4 * P + 2);
 }
 
 // ---- [C Z] <- (I - V_p T_p' V_p') [C Z] on the row tiles t >= 2P ---------------------------------------------------
@@ -323,50 +346,244 @@ __device__ __forceinline__ void qrb_apply(d4 (&c)[8], d4 (&z)[8], const QbLds &L
             }
     }
     QB_BARRIER();  // Vs, Ts, Wx are free again
+    QRB_STAMP(8 + 4 * P + 3);
 }
 
 // column jj of the panel's compact-WY triangle (dlarft, forward / columnwise): T[0:jj, jj] = -tau T[0:jj, 0:jj] V[:, 0:jj]' v_jj.
-// dots[k] = u_k' u_jj for the finished columns k < jj; T-hat = T diag(1/xi) stays in LDS.  One wave, lanes 0..31 = rows.
+// dots[k] = u_k' u_jj for the finished columns k < jj (entries k >= jj are other columns' dot products: they meet zeros of
+// T-hat); T-hat = T diag(1/xi) stays in LDS.  One wave, lanes 0..31 = rows; all requests first, then the sums.
 template <int W>
-__device__ __forceinline__ void qrb_tcolumn(const QbLds &L, qword *mb, unsigned tag, bool local, int lane, int jj)
+__device__ __forceinline__ void qrb_tcolumn(const QbLds &L, qword *mb, unsigned tag, bool local, int lane, int jj, bool publish = true)
 {
+    // lanes (row c = lane & 31, half h = lane >> 5): half h sums over k in [16 h, 16 h + 16); the halves meet with one
+    // v_permlane32_swap (the 48 LDS reads of a 32-lane form made this the longest job of a step: LDS passes, not arithmetic)
+    const int cl = lane & 31, h = lane >> 5;
+    const double2 *dots = reinterpret_cast<const double2 *>(L.dotbuf + (jj & 1) * 32 + 16 * h);
+    const double2 *th = reinterpret_cast<const double2 *>(L.Th + cl * UST + 16 * h);
+    double2 dd[8], tt[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        dd[k] = dots[k];
+        tt[k] = th[k];
+    }
+    const double tau = L.rcps[32 + 2 * jj], rcp = L.rcps[jj];
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        a0 = __builtin_fma(tt[k].x, dd[k].x, a0);
+        a1 = __builtin_fma(tt[k].y, dd[k].y, a1);
+    }
+    const double part = a0 + a1;
+    const int plo = __double2loint(part), phi = __double2hiint(part);
+    const auto slo = __builtin_amdgcn_permlane32_swap(plo, plo, false, false);
+    const auto shi = __builtin_amdgcn_permlane32_swap(phi, phi, false, false);
+    const double acc = part + __hiloint2double((int)shi[1], (int)slo[1]);  // (lanes 0..31: + the sum of lanes 32..63)
     if (lane < 32) {
-        const double *dots = L.dotbuf + (jj & 1) * 32;
-        const double *th = L.Th + lane * UST;
-        double acc = 0.0;
-        for (int k = 0; k < jj; k += 2) {
-            const double2 dd = *reinterpret_cast<const double2 *>(dots + k);
-            const double2 tt = *reinterpret_cast<const double2 *>(th + k);
-            acc = __builtin_fma(tt.x, dd.x, acc);
-            acc = __builtin_fma(tt.y, k + 1 < jj ? dd.y : 0.0, acc);
-        }
-        const double tau = L.rcps[32 + jj], rcp = L.rcps[jj];
         const double t = lane < jj ? -(tau * rcp) * acc : (lane == jj ? tau : 0.0);
         L.Th[lane * UST + jj] = t * rcp;
-        if (*L.s_abort != 2) g_put_sel(mb + 2 * (MB_T + ((long)W * 32 + jj) * 32 + lane), t, tag, local);
+        if (publish && abort_get(L.s_abort) != 2) g_put_sel(mb + 2 * (MB_T + ((long)W * 32 + jj) * 32 + lane), t, tag, local);
     }
+}
+
+__device__ __forceinline__ double qmovdpp_b1(double x)  // quad_perm [1,0,3,2]
+{
+    return __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(x), 0xB1, 0xf, 0xf, true),
+                            __builtin_amdgcn_mov_dpp(__double2loint(x), 0xB1, 0xf, 0xf, true));
+}
+__device__ __forceinline__ double qmovdpp_4e(double x)  // quad_perm [2,3,0,1]
+{
+    return __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(x), 0x4E, 0xf, 0xf, true),
+                            __builtin_amdgcn_mov_dpp(__double2loint(x), 0x4E, 0xf, 0xf, true));
+}
+__device__ __forceinline__ double qmovdpp_hm(double x)  // row_half_mirror
+{
+    return __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(x), 0x141, 0xf, 0xf, true),
+                            __builtin_amdgcn_mov_dpp(__double2loint(x), 0x141, 0xf, 0xf, true));
+}
+// sum over the 8 lanes {8g .. 8g+7} (every source lane is valid: no old value to prepare)
+__device__ __forceinline__ double qsum8b(double x)
+{
+    x += qmovdpp_b1(x);
+    x += qmovdpp_4e(x);
+    x += qmovdpp_hm(x);
+    return x;
 }
 
 // ---- panel W factored by its owner -------------------------------------------------------------------------------
 // thread (pc = tid >> 3, rg = tid & 7) holds column pc of the panel, rows 16 (k >> 1) + 2 rg + (k & 1), k = 0..31 (rows below
-// 32 W carry finished R entries).  Step j: the owner's 8 lanes give the norm and the reflector scalars (UDT.jl:133-148) and
-// leave the UNSCALED reflector u = xi v in LDS; after ONE barrier every column takes its dot product with u and is updated
-// (finished columns with coefficient 0: their dot products are V' v_j, the raw material of T).  While the NEXT owner wave
-// works on its norm and scalars, two other waves publish v_j = u / xi with diag R, and column j - 1 of T.
+// 32 W carry finished R entries).  The 32 steps are four ERAS of eight: in era E wave E owns the pivot columns, and every
+// wave runs straight-line code for its role of the era (taken branches cost ~50 cycles each on a lone wave - measured with
+// in-kernel stamps - so roles, register choices and buffer parities are template constants, not run-time tests):
+//   role 0 (wave E)      [A](j): norm over the 8 lanes of the column, nu / xi / beta = 1 / (nu xi) (UDT.jl:133-148 with
+//                        H = I - beta u u', u = xi v: no scaling pass), diagonal entry patched into the reflector that has
+//                        been in LDS since the end of the previous step; then, like everybody, ONE barrier and
+//                        [B](j): dot with u, update (finished columns with coefficient 0: their dot products are V' v_j),
+//                        the finished row g leaves x for r, and the next column goes to LDS as the next raw reflector;
+//   role 1 (wave E + 1)  [B], then v_j = u / xi to the mailbox (at the era's last step: the raw reflector of ITS first column);
+//   role 2 (wave E + 2)  [B], then column j - 1 of T (dlarft recurrence);
+//   role 3 (wave E + 3)  [B], then diag R and 1 / D (at the era's last step also v_j, for role 1).
+struct QbStepCtx {
+    qword *mb;
+    unsigned tag;
+    bool local, real;
+    int lane, pc, rg, stop_at;
+};
+
 template <int W>
-__device__ __forceinline__ void qrb_own(d4 (&c)[8], const QbLds &L, qword *mb, unsigned tag, bool local, int tid,
+__device__ __forceinline__ void qrb_publish_v(const QbLds &L, const QbStepCtx &C, int par, int j)
+{
+    constexpr int NI = (256 - 32 * W + 63) / 64;
+    const int g = 32 * W + j;
+    const double xi = L.scal[par * 2 + 1];
+    double u[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int row = min(32 * W + C.lane + 64 * i, 255);
+        u[i] = L.ub[(par * 8 + ((row & 15) >> 1)) * UST + 2 * (row >> 4) + (row & 1)];
+    }
+    const double rcp = q_rcp(xi);
+    const bool quiet = abort_get(L.s_abort) == 2 || !C.real;  // forced time-out: nothing is published any more
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int row = 32 * W + C.lane + 64 * i;
+        if (row < 256) {
+            const double v = row > g ? u[i] * rcp : (row == g ? 1.0 : 0.0);
+            if (!quiet) g_put_sel(C.mb + 2 * (MB_V + ((long)W * 32 + j) * 256 + row), v, C.tag, C.local);
+        }
+    }
+    if (C.lane == 0) L.rcps[j] = rcp;
+}
+
+template <int W, int E, int ROLE, int ODD>
+__device__ __forceinline__ void qrb_step(double (&x)[32], double (&r)[4], const QbLds &L, const QbStepCtx &C, int j)
+{
+    constexpr int KB0 = 4 * W, JB = E >> 1, KK = KB0 + 2 * JB + ODD;  // x[KK] holds row g in the lane with rg == (j & 15) >> 1
+    const int g = 32 * W + j, rgo = (j & 15) >> 1;
+    const bool last = (j & 7) == 7;  // last step of the era
+    double *ug = L.ub + (ODD * 8 + rgo) * UST + KK;  // LDS word of row g in the reflector buffer
+    if (j == C.stop_at && C.lane == 0) abort_set(L.s_abort, 2);  // test hook: this part stops publishing
+    if (ROLE == 0) {
+        // every column group of the wave runs the same chain on its own norm; only the owner's results are stored
+        const double xi1 = *ug;  // (broadcast read; the raw column is there since the end of the previous step)
+        double n0 = 0.0, n1 = 0.0;
+#pragma unroll
+        for (int k = KB0; k < 32; k += 2) {
+            n0 = __builtin_fma(x[k], x[k], n0);
+            n1 = __builtin_fma(x[k + 1], x[k + 1], n1);
+        }
+        const double maxval = qsum8b(n0 + n1);
+        // UDT.jl:133-148 (a zero column gives NaN here where the reference gives tau = 0 and then 1 / D = Inf)
+        double rootn, rrootn;
+#ifdef QRB_T_NOSCAL
+        rootn = maxval; rrootn = maxval + 1.0;
+#else
+        q_sqrt_rsqrt(maxval, rootn, rrootn);
+#endif
+        const double nu = copysign(rootn, xi1);
+        const double xi = xi1 + nu;
+        const double tj = __builtin_fma(fabs(xi1), rrootn, 1.0);  // xi / nu
+#ifdef QRB_T_NOSCAL
+        const double beta = nu * xi;
+#else
+        const double beta = q_rcp(nu * xi);                       // tau / xi^2
+#endif
+        if (C.lane == 8 * (j & 7)) {
+            *ug = xi;
+            *reinterpret_cast<double2 *>(L.scal + ODD * 2) = make_double2(beta, xi);
+            *reinterpret_cast<double2 *>(L.rcps + 32 + 2 * j) = make_double2(tj, nu);
+        }
+    }
+#ifdef QRB_T_NOBAR
+    if (C.real) QB_BARRIER();
+#else
+    QB_BARRIER();
+#endif
+    {
+        const double beta = L.scal[ODD * 2];
+        const double2 *uq = reinterpret_cast<const double2 *>(L.ub + (ODD * 8 + C.rg) * UST);
+        double2 uu[16];
+        double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+        for (int k = KB0; k < 32; k += 2) {
+            uu[k >> 1] = uq[k >> 1];
+            d0 = __builtin_fma(uu[k >> 1].x, x[k], d0);
+            d1 = __builtin_fma(uu[k >> 1].y, x[k + 1], d1);
+        }
+        const double dot = qsum8b(d0 + d1);
+        if (C.rg == 0) L.dotbuf[ODD * 32 + C.pc] = dot;
+        const bool live = C.pc > j;
+        const double coef = live ? dot * beta : 0.0;
+#pragma unroll
+        for (int k = KB0; k < 32; k += 2) {
+            x[k] = __builtin_fma(-uu[k >> 1].x, coef, x[k]);
+            x[k + 1] = __builtin_fma(-uu[k >> 1].y, coef, x[k + 1]);
+        }
+        // row g of the live columns is finished: it leaves x (one lane per column)
+        const bool mine = live & (C.rg == rgo);
+        r[2 * JB + ODD] = mine ? x[KK] : r[2 * JB + ODD];
+        x[KK] = mine ? 0.0 : x[KK];
+    }
+#ifdef QRB_T_NOHELP
+    if (ROLE != 0 && !C.real) return;
+#endif
+    if (ROLE == 0) {
+        // the next column's raw reflector goes to LDS at once (its diagonal entry is patched when xi is known)
+        if (!last && (C.lane >> 3) == ((j + 1) & 7)) {
+            double2 *dst = reinterpret_cast<double2 *>(L.ub + ((ODD ^ 1) * 8 + C.rg) * UST);
+#pragma unroll
+            for (int k = KB0; k < 32; k += 2) dst[k >> 1] = make_double2(x[k], x[k + 1]);
+        }
+    } else if (ROLE == 1) {
+        if (last && E < 3) {  // my first column is the next pivot column
+            if (C.lane < 8) {
+                double2 *dst = reinterpret_cast<double2 *>(L.ub + ((ODD ^ 1) * 8 + C.rg) * UST);
+#pragma unroll
+                for (int k = KB0; k < 32; k += 2) dst[k >> 1] = make_double2(x[k], x[k + 1]);
+            }
+        } else {
+            qrb_publish_v<W>(L, C, ODD, j);
+        }
+    } else if (ROLE == 2) {
+        if (j >= 1) qrb_tcolumn<W>(L, C.mb, C.tag, C.local, C.lane, j - 1, C.real);
+    } else {
+        if (C.lane == 0) {  // diag R and 1 / D
+            const double nu = L.rcps[32 + 2 * j + 1];
+            const double an = fabs(nu);
+            L.dval[j] = an;
+            L.dinv[g] = q_rcp(an);
+            if (abort_get(L.s_abort) != 2 && C.real) g_put_sel(C.mb + 2 * (MB_D + g), -nu, C.tag, C.local);
+        }
+        if (last && E < 3) qrb_publish_v<W>(L, C, ODD, j);
+    }
+}
+
+template <int W, int E, int ROLE>
+__device__ __forceinline__ void qrb_era_role(double (&x)[32], double (&r)[4], const QbLds &L, const QbStepCtx &C)
+{
+    for (int jp = 0; jp < 4; ++jp) {
+        qrb_step<W, E, ROLE, 0>(x, r, L, C, 8 * E + 2 * jp);
+        qrb_step<W, E, ROLE, 1>(x, r, L, C, 8 * E + 2 * jp + 1);
+    }
+}
+template <int W, int E>
+__device__ __forceinline__ void qrb_era(double (&x)[32], double (&r)[4], const QbLds &L, const QbStepCtx &C, int wv)
+{
+    switch ((wv - E) & 3) {
+    case 0: qrb_era_role<W, E, 0>(x, r, L, C); break;
+    case 1: qrb_era_role<W, E, 1>(x, r, L, C); break;
+    case 2: qrb_era_role<W, E, 2>(x, r, L, C); break;
+    default: qrb_era_role<W, E, 3>(x, r, L, C); break;
+    }
+}
+
+template <int W>
+__device__ __forceinline__ void qrb_own(d4 (&c)[8], d4 (&z)[8], const QbLds &L, qword *mb, unsigned tag, bool local, int tid,
                                         double *__restrict__ Tout, int apply_pivot, int force_timeout, int part)
 {
-#ifdef QRB_X_NOOWN
-    return;
-#endif
     constexpr int KB0 = 4 * W;
-    constexpr int NI = (256 - 32 * W + 63) / 64;
-    const int wv = tid >> 6, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;  // (scalar: the role switch is s_cmp, not exec masks)
+    QRB_STAMP(48);
     // accumulator layout -> panel layout through the (free) panel buffer
-#ifdef QRB_X_NOPS
-    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-#endif
     {
         const int nn = lane & 15, kq = lane >> 4, ct = wv & 1, rh = wv >> 1;
         double *cs = L.Vs + (16 * ct + nn) * VLD + kq;
@@ -391,131 +608,77 @@ __device__ __forceinline__ void qrb_own(d4 (&c)[8], const QbLds &L, qword *mb, u
             x[k + 1] = a.y;
         }
     }
-    for (int j = 0; j < 32; ++j) {
-        const int par = j & 1, g = 32 * W + j;
-        if (force_timeout >= 2 && part == 3 && j == ((force_timeout - 2) & 31)) {
-            // test hook: this part stops publishing, as a workgroup that lost its CU would
-            if (tid == 0) *L.s_abort = 2;
-        }
-        if (wv == (j >> 3)) {
-            double n0 = 0.0, n1 = 0.0, xg = 0.0;
-#pragma unroll
-            for (int k = KB0; k < 32; k += 2) {
-                if (k < KB0 + 4) {
-                    const int ra = 32 * W + 16 * ((k - KB0) >> 1) + 2 * rg;
-                    n0 += (ra >= g ? 1.0 : 0.0) * (x[k] * x[k]);
-                    n1 += (ra + 1 >= g ? 1.0 : 0.0) * (x[k + 1] * x[k + 1]);
-                    xg += (ra == g ? x[k] : 0.0) + (ra + 1 == g ? x[k + 1] : 0.0);
-                } else {
-                    n0 = __builtin_fma(x[k], x[k], n0);
-                    n1 = __builtin_fma(x[k + 1], x[k + 1], n1);
-                }
-            }
-            const int ol = 8 * (j & 7);
-            const double maxval = qreadlane(qsum8(n0 + n1), ol), xi1 = qreadlane(qsum8(xg), ol);
-            // UDT.jl:133-148, branch-free (a zero column keeps tau = 0 and stays as it is)
-            const bool nz = maxval != 0.0;
-            double rootn, rrootn;
-            q_sqrt_rsqrt(nz ? maxval : 1.0, rootn, rrootn);
-            const double nu = nz ? copysign(rootn, xi1) : -xi1;
-            const double xi = nz ? xi1 + nu : 1.0;
-            const double tj = nz ? __builtin_fma(fabs(xi1), rrootn, 1.0) : 0.0;  // xi / nu
-            const double rcp = q_rcp(xi), trr = tj * rcp;
-            if ((lane >> 3) == (j & 7)) {
-                double2 *dst = reinterpret_cast<double2 *>(L.ub + (par * 8 + rg) * UST);
-#pragma unroll
-                for (int k = KB0; k < 32; k += 2) {
-                    double a = x[k], b = x[k + 1];
-                    if (k < KB0 + 4) {
-                        const int ra = 32 * W + 16 * ((k - KB0) >> 1) + 2 * rg;
-                        a = ra > g ? a : (ra == g ? xi : 0.0);
-                        b = ra + 1 > g ? b : (ra + 1 == g ? xi : 0.0);
-                        x[k] = ra == g ? -nu : x[k];
-                        x[k + 1] = ra + 1 == g ? -nu : x[k + 1];
-                    }
-                    dst[k >> 1] = make_double2(a, b);
-                }
-                if (rg == 0) {
-                    *reinterpret_cast<double2 *>(L.scal + par * 2) = make_double2(rcp, trr);
-                    L.rcps[j] = rcp;
-                    L.rcps[32 + j] = tj;
-                    L.rcps[64 + j] = nu;
-                }
-            }
-        }
-        QB_BARRIER();
-        {
-            const double2 sc = *reinterpret_cast<const double2 *>(L.scal + par * 2);
-            const double2 *uq = reinterpret_cast<const double2 *>(L.ub + (par * 8 + rg) * UST);
-            double2 uu[16];
-            double d0 = 0.0, d1 = 0.0;
-#pragma unroll
-            for (int k = KB0; k < 32; k += 2) {
-                uu[k >> 1] = uq[k >> 1];
-                d0 = __builtin_fma(uu[k >> 1].x, x[k], d0);
-                d1 = __builtin_fma(uu[k >> 1].y, x[k + 1], d1);
-            }
-            const double dot = qsum8(d0 + d1);
-            if (rg == 0) L.dotbuf[par * 32 + pc] = dot;
-            const double coef = pc > j ? (dot * sc.x) * sc.y : 0.0;
-#pragma unroll
-            for (int k = KB0; k < 32; k += 2) {
-                x[k] = __builtin_fma(-uu[k >> 1].x, coef, x[k]);
-                x[k + 1] = __builtin_fma(-uu[k >> 1].y, coef, x[k + 1]);
-            }
-        }
-        // in the shadow of the next owner's norm and scalars
-        const int on = ((j + 1) >> 3) & 3;
-        if (wv == ((on + 1) & 3)) {  // v_j = u / xi and diag R, to the mailbox
-            const double rcp = L.rcps[j];
-            const bool quiet = *L.s_abort == 2;  // forced time-out: nothing is published any more
-#pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int row = 32 * W + lane + 64 * i;
-                if (row < 256) {
-                    const double u = L.ub[(par * 8 + ((row & 15) >> 1)) * UST + 2 * (row >> 4) + (row & 1)];
-                    const double v = row > g ? u * rcp : (row == g ? 1.0 : 0.0);
-                    if (!quiet) g_put_sel(mb + 2 * (MB_V + ((long)W * 32 + j) * 256 + row), v, tag, local);
-                }
-            }
-            if (lane == 0) {
-                const double nu = L.rcps[64 + j];
-                L.dval[j] = fabs(nu);
-                L.dinv[g] = 1.0 / fabs(nu);
-                if (!quiet) g_put_sel(mb + 2 * (MB_D + g), -nu, tag, local);
-            }
-        } else if (wv == ((on + 2) & 3) && j >= 1) {
-            qrb_tcolumn<W>(L, mb, tag, local, lane, j - 1);
-        }
-    }
+    // Z waits in the panel buffer while the panel is factored (64 registers less through the steps)
     QB_BARRIER();
-    if (wv == 0) qrb_tcolumn<W>(L, mb, tag, local, lane, 31);
-#ifdef QRB_X_DUMP2
-    if (W == 1) {
+    {
+        double *zs = L.Vs + tid;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            qrb_dump[tid * 4 + k] = x[k];
-            qrb_dump[1024 + tid * 4 + k] = L.dinv[16 * (k >> 1) + 2 * rg + (k & 1)];
-        }
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) zs[(4 * u + q) * 256] = z[u][q];
+    }
+    // Rows of the diagonal block that are finished leave x: r[kk] takes R[32 W + 16 (kk >> 1) + 2 rg + (kk & 1), my column]
+    // and the register is zeroed, so that neither the norms nor the reflectors written to LDS need a mask.
+    double r[4] = {0.0, 0.0, 0.0, 0.0};
+    // the first column's raw reflector
+    if (tid < 8) {
+        double2 *dst = reinterpret_cast<double2 *>(L.ub + rg * UST);
+#pragma unroll
+        for (int k = KB0; k < 32; k += 2) dst[k >> 1] = make_double2(x[k], x[k + 1]);
+    }
+    QRB_STAMP(49);
+    QbStepCtx C;
+    C.mb = mb; C.tag = tag; C.local = local; C.real = true; C.lane = lane; C.pc = pc; C.rg = rg;
+    C.stop_at = (force_timeout >= 2 && force_timeout < 1000 && part == 3) ? ((force_timeout - 2) & 31) : -1;
+#ifdef QRB_X_EXTRA  // timing experiment (results are garbage): the 32 steps are run again without publishing
+    for (int rep = 0; rep < 1 + (force_timeout >= 1000 ? force_timeout - 1000 : 0); ++rep) {
+        C.real = rep == 0;
+#endif
+        qrb_era<W, 0>(x, r, L, C, wv);
+        QRB_STAMP(50);
+        qrb_era<W, 1>(x, r, L, C, wv);
+        QRB_STAMP(51);
+        qrb_era<W, 2>(x, r, L, C, wv);
+        QRB_STAMP(52);
+        qrb_era<W, 3>(x, r, L, C, wv);
+#ifdef QRB_X_EXTRA
     }
 #endif
-    // T = D^-1 R of my column: rows <= its position (UDT.jl:283-306), zeros below
+    QB_BARRIER();
+    QRB_STAMP(53);
+    {
+        const double *zs = L.Vs + tid;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) z[u][q] = zs[(4 * u + q) * 256];
+    }
+    if (wv == 0) qrb_tcolumn<W>(L, mb, tag, local, lane, 31);
+    // T = D^-1 R of my column: rows <= its position (UDT.jl:283-306), zeros below.  Rows above the panel are in x, the rows of
+    // the diagonal block above the diagonal in r, the diagonal entry is -nu
     {
         const int gc = 32 * W + pc;  // position of my column
         const int dc = apply_pivot ? L.ord[gc] : gc;
+        const double nu_c = L.rcps[32 + 2 * pc + 1];
         double2 *tcol = reinterpret_cast<double2 *>(Tout + (long)256 * dc + 2 * rg);
 #pragma unroll
         for (int k = 0; k < 32; k += 2) {
             const int ra = 16 * (k >> 1) + 2 * rg;
             double a = 0.0, b = 0.0;
-            if (k < KB0 + 4) {
+            if (k < KB0) {
                 const double2 di = *reinterpret_cast<const double2 *>(L.dinv + ra);
-                a = ra <= gc ? x[k] * di.x : 0.0;
-                b = ra + 1 <= gc ? x[k + 1] * di.y : 0.0;
+                a = x[k] * di.x;
+                b = x[k + 1] * di.y;
+            } else if (k < KB0 + 4) {
+                const double2 di = *reinterpret_cast<const double2 *>(L.dinv + ra);
+                const double va = ra == gc ? -nu_c : r[k - KB0], vb = ra + 1 == gc ? -nu_c : r[k - KB0 + 1];
+                a = ra <= gc ? va * di.x : 0.0;
+                b = ra + 1 <= gc ? vb * di.y : 0.0;
             }
             tcol[4 * k] = make_double2(a, b);
         }
     }
+    QRB_STAMP(54);
 }
 
 // the program of part W: panels in order, my own panel in between.  (W is a template constant so that the compiler sees
@@ -526,7 +689,7 @@ __device__ __forceinline__ void qrb_panel(d4 (&c)[8], d4 (&z)[8], const QbLds &L
 {
     const int wv = tid >> 6, lane = tid & 63;
     if (P == W) {
-        qrb_own<P>(c, L, mb, tag, local, tid, Tout, apply_pivot, force_timeout, W);
+        qrb_own<P>(c, z, L, mb, tag, local, tid, Tout, apply_pivot, force_timeout, W);
         QB_BARRIER();
         if (P > 0) {  // the update of Z that made way for my panel
             qrb_fetch<(P > 0 ? P - 1 : 0)>(mb, tag, L, tid);
@@ -594,7 +757,8 @@ __global__ __launch_bounds__(QB_THREADS) void qrb_udt_kernel(int n_units, const 
         int *q = reinterpret_cast<int *>(p);
         L.ord = q; q += 256;
         L.xcc = q; q += 8;
-        L.s_abort = q;
+        L.s_abort = q; q += 4;
+        L.fst = reinterpret_cast<long long *>(q);
     }
     const int bid = blockIdx.x, xcd = bid & 7, seq = bid >> 3;
     const int unit = (seq / 8) * 8 + xcd, part = seq % 8;
@@ -602,7 +766,12 @@ __global__ __launch_bounds__(QB_THREADS) void qrb_udt_kernel(int n_units, const 
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const double *__restrict__ A = Aall + (long)unit * strideA;
     qword *mb = mailbox + (long)unit * MB_GRANULES * 2;
-    if (tid == 0) *L.s_abort = 0;
+    L.stamps = nullptr;
+#ifdef QRB_STAMPS
+    if (unit == 0 && qrb_stamp_ptr) L.stamps = qrb_stamp_ptr + part * 64;
+#endif
+    QRB_STAMP(0);
+    if (tid == 0) abort_set(L.s_abort, 0);
     if (force_timeout == 1) {  // test hook: a launch whose hand-offs all time out at once
         if (tid == 0) atomicOr(errflag, 16);
         return;
@@ -627,10 +796,12 @@ __global__ __launch_bounds__(QB_THREADS) void qrb_udt_kernel(int n_units, const 
         const unsigned my_xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 0xfu;  // HW_REG_XCC_ID[3:0]
         g_put<false>(mb + 2 * (MB_X + part), (double)my_xcc, tag);
     }
+    QRB_STAMP(1);
     L.nrm[tid] = g_wait(mb + 2 * (MB_N + tid), tag, L.s_abort);
     L.ord[tid] = tid;
     if (tid < 8) L.xcc[tid] = (int)g_wait(mb + 2 * (MB_X + tid), tag, L.s_abort);
     __syncthreads();
+    QRB_STAMP(2);
     bool local = force_sc1 == 0;
 #pragma unroll
     for (int q = 1; q < 8; ++q) local = local && L.xcc[q] == L.xcc[0];
@@ -647,6 +818,7 @@ __global__ __launch_bounds__(QB_THREADS) void qrb_udt_kernel(int n_units, const 
         L.ord[rank & 255] = tid;  // (ranks are a permutation unless a norm is NaN; ord starts as the identity)
     }
     __syncthreads();
+    QRB_STAMP(3);
     if (part == 0) pivall[(long)unit * 256 + tid] = L.ord[tid];
 
     // ---- my 32 columns (positions 32 part ..) in accumulator layout; Z = my columns of the identity ----
@@ -665,6 +837,7 @@ __global__ __launch_bounds__(QB_THREADS) void qrb_udt_kernel(int n_units, const 
             }
     }
     double *__restrict__ Tout = Tall + (long)unit * strideT;
+    QRB_STAMP(4);
     switch (part) {
     case 0: qrb_part<0>(c, z, L, mb, tag, local, tid, Tout, apply_pivot, force_timeout); break;
     case 1: qrb_part<1>(c, z, L, mb, tag, local, tid, Tout, apply_pivot, force_timeout); break;
@@ -686,8 +859,21 @@ __global__ __launch_bounds__(QB_THREADS) void qrb_udt_kernel(int n_units, const 
             for (int r = 0; r < 4; ++r) uo[(long)256 * (16 * (2 * u + rh) + 4 * r + kq)] = z[u][r];
     }
     if (tid < 32) Dall[(long)unit * strideD + 32 * part + tid] = L.dval[tid];
-    if (tid == 0 && *L.s_abort) atomicOr(errflag, 16);
+    QRB_STAMP(60);
+    if (tid == 0 && abort_get(L.s_abort)) atomicOr(errflag, 16);
 }
+#ifdef QRB_FINE
+extern "C" int dqmc_debug_qrb_fine(void *devptr)
+{
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(qrb_fine_ptr), &devptr, sizeof(void *));
+}
+#endif
+#ifdef QRB_STAMPS
+extern "C" int dqmc_debug_qrb_stamps(void *devptr)
+{
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(qrb_stamp_ptr), &devptr, sizeof(void *));
+}
+#endif
 
 #if defined(QRB_X_DUMP) || defined(QRB_X_DUMP2)
 extern "C" int dqmc_debug_qrb_dump(double *host)
@@ -698,7 +884,11 @@ extern "C" int dqmc_debug_qrb_dump(double *host)
 size_t qrb_lds_bytes()
 {
     return (size_t)(32 * VLD + 32 * TLD + 4 * 16 * 64 + 2 * 8 * UST + 4 + 64 + 32 * UST + 96 + 256 + 32 + 256) * sizeof(double) +
-           (256 + 8 + 4) * sizeof(int);
+           (256 + 8 + 4) * sizeof(int)
+#ifdef QRB_FINE
+           + 4 * 32 * 8 * sizeof(long long)
+#endif
+        ;
 }
 size_t qrb_mailbox_bytes(int n_units) { return (size_t)((n_units + 7) / 8) * 8 * MB_GRANULES * 16; }
 
