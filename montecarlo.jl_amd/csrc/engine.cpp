@@ -51,36 +51,18 @@ struct dqmc_handle {
     // scratch of one UDT (udt_AVX_pivot!): V (Householder vectors; hand-over buffer of the two-phase QR before that),
     // W (factored matrix of the cooperative QR, then the compact-WY product), S (V'V), tau, pivot, and what the
     // triangular solves need (winv: inverted 16 x 16 diagonal blocks; ts: n > 256, panel-solved copy of the right-hand
-    // side).  Two sets, so that the Q formation of one decomposition can run on the auxiliary stream while the next
-    // factorisation already runs on the main one; the auxiliary stream has solve scratch of its own (aux_winv / aux_ts).
+    // side).
     struct QrSet {
         double *V = nullptr, *W = nullptr, *S = nullptr, *tau = nullptr, *winv = nullptr, *ts = nullptr;
         int *pivot = nullptr;
-    } qs[2];
-    double *aux_winv = nullptr, *aux_ts = nullptr;
+    } qs[1];
     double *&qrV = qs[0].V, *&qrW = qs[0].W, *&qrS = qs[0].S, *&trsm_w = qs[0].winv, *&trsm_s = qs[0].ts, *&tau = qs[0].tau;
     int *&pivot = qs[0].pivot;
     double *Dl = nullptr, *Dr = nullptr;
-    // Independent kernels of one stabilisation step run side by side (stack.jl:519-550, 585-614 have no such notion:
-    // one thread): `cur` is the stream the launch helpers use (stream, or aux inside a forked region).
-    hipStream_t aux = nullptr, cur = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    bool overlap = false, aux_pending = false;
-    bool overlap_rdivp = false;  // DQMC_OVERLAP_RDIVP: rdivp! next to the Q formation before it (two 120 KB-LDS TRSM kernels
-                                 // cannot share a CU: measured no gain, off by default)
-    // slice-matrix chain of the NEXT stack interval, advanced by one product after every sweep_spatial (aux stream)
-    struct {
-        bool valid = false;
-        int dir = 0, idx = 0, next_t = 0;   // products 0 .. next_t - 1 of interval idx are done
-        double *buf[2] = {nullptr, nullptr};
-        double *out = nullptr;
-    } chain;
+    hipStream_t cur = nullptr;  // the stream the launch helpers use (= stream)
     double *sU = nullptr, *sVT = nullptr;
     double *greens_alt = nullptr, *lu_img = nullptr;  // decide / apply sweep (sweep_lu.hip)
     bool sweep_lu = true, sweep_fused = true;
-    bool sweep_persist = false;        // one launch per time slice (sweep_slice_kernel)
-    unsigned *slice_flags = nullptr;   // its hand-over words
-    unsigned slice_launch = 0;         // launches so far (the tags grow monotonically)
     WalkerRng *rng = nullptr;
     DevStats *stats = nullptr;
     unsigned long long *pc_scratch = nullptr;  // prop_check_kernel: partial maximum + arrival counter per walker
@@ -333,7 +315,6 @@ static int alloc_qr_workspace(dqmc_handle *h)
     if (const char *e = getenv("DQMC_QR_TAIL")) h->qr_ws.tail_j0 = atoi(e);  // A/B switches, read per handle
     h->qr_ws.force_sc1 = getenv("DQMC_QR_SC1") != nullptr;
     h->qr_ws.no_coop = getenv("DQMC_QR_NOCOOP") != nullptr;
-    h->qr_ws.rows = getenv("DQMC_QR_ROWS") != nullptr && qr_rows_blocks_per_cu() >= 1;
     if (const char *e = getenv("DQMC_QR_FORCE_TIMEOUT"))
         h->qr_ws.force_timeout = strncmp(e, "step:", 5) == 0 ? 2 + atoi(e + 5) : (strncmp(e, "extra:", 6) == 0 ? 1000 + atoi(e + 6) : 1);
     // pre-pivoted blocked UDT in one launch (qrb.hip): n == 256, all eight workgroups of every unit co-resident.
@@ -366,33 +347,6 @@ static int check_qr_workspace(dqmc_handle *h)
                                                "such requirement)"
                                              : "sweep elimination: hand-off timed out (results of this call are invalid)");
     }
-    return 0;
-}
-
-// ---- fork / join of the auxiliary stream -----------------------------------------
-// fork: what is launched on h->cur (= aux) until aux_end() runs after everything issued to the main stream so far;
-// join: the main stream waits for everything issued to aux so far.  Without an auxiliary stream (stand-alone
-// primitives, DQMC_NO_OVERLAP) the region simply runs on the main stream, in program order.
-static int aux_begin(dqmc_handle *h)
-{
-    if (!h->overlap) return 0;
-    HIPCHK(hipEventRecord(h->ev_fork, h->stream));
-    HIPCHK(hipStreamWaitEvent(h->aux, h->ev_fork, 0));
-    h->cur = h->aux;
-    return 0;
-}
-static void aux_end(dqmc_handle *h)
-{
-    if (!h->overlap) return;
-    h->cur = h->stream;
-    h->aux_pending = true;
-}
-static int aux_join(dqmc_handle *h)
-{
-    if (!h->overlap || !h->aux_pending) return 0;
-    HIPCHK(hipEventRecord(h->ev_join, h->aux));
-    HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
-    h->aux_pending = false;
     return 0;
 }
 
@@ -465,33 +419,23 @@ static int rdivp(dqmc_handle *h, double *A, const double *T)
 // L = (Ul, Dl, Tl), R = (Ur, Dr, Tr) are only read (they may be stack slots); h->Ul .. h->Tr are the work matrices
 // the reference overwrites its six inputs with.  L / R may also BE those work matrices (each is consumed before the
 // step that overwrites it).
-// Two kernels that do not depend on each other run side by side (overlap mode): each rdivp! next to the Q formation
-// of the decomposition before it.  On entry the Q of L or R may still be in flight on the auxiliary stream
-// (add_slice_sequence_*): it is awaited after the first factorisation, before L.u / R.u are read.
 static int calculate_greens_src(dqmc_handle *h, double *out, Udt L, Udt R)
 {
     const int n = h->n;
-    QrSet &qa = h->overlap ? h->qs[1] : h->qs[0], &qb = h->qs[0];
-    const bool ov = h->overlap && h->overlap_rdivp;
-    double *winv_x = ov ? h->aux_winv : nullptr, *ts_x = ov ? h->aux_ts : nullptr;
+    QrSet &qa = h->qs[0], &qb = h->qs[0];
     GemmArgs g = gemm_base(h, U_(h, L.t), 0, U_(h, R.t), 1, out);  // :346-348
     g.colscale = vs_arr(R.d, n);
     g.rowscale = vs_arr(L.d, n);
     CHK(run_gemm(h, g));
     if (udt_is_fused(h, 1)) {                                          // :349 in one launch (T out of place, in qa.W)
         CHK(udt_fused(h, out, h->Tr, h->Dr, qa.W, 0, qa));
-        CHK(aux_join(h));
         CHK(rdivp_set(h, R.u, qa.W, h->Ur, qa, qa.winv, qa.ts));       // :361
     } else {
     CHK(udt_factor(h, out, h->Dr, nullptr, 0, qa));                    // :349, first half
-    CHK(aux_join(h));                                                  // L.u / R.u of a slot whose Q was still being formed
-    if (ov) CHK(aux_begin(h));                                         // :361 (out of place: Ur = R.u[:, p] / T)
-    CHK(rdivp_set(h, R.u, out, h->Ur, qa, ov ? winv_x : qa.winv, ov ? ts_x : qa.ts));
-    if (ov) aux_end(h);
+    CHK(rdivp_set(h, R.u, out, h->Ur, qa, qa.winv, qa.ts));            // :361 (out of place: Ur = R.u[:, p] / T)
     CHK(udt_formq(h, h->Tr, qa, qa.winv, qa.ts));                      // :349, second half
     }
     CHK(run_gemm(h, gemm_base(h, U_(h, L.u), 0, U_(h, h->Tr), 0, h->Tl)));    // :360
-    CHK(aux_join(h));
     g = gemm_base(h, U_(h, h->Tl), 1, U_(h, h->Ur), 0, h->Tr);         // :362 + :368
     g.adddiag = vs_arr(h->Dr, n);
     CHK(run_gemm(h, g));
@@ -500,12 +444,9 @@ static int calculate_greens_src(dqmc_handle *h, double *out, Udt L, Udt R)
         CHK(rdivp_set(h, h->Ur, qb.W, h->Ur, qb, qb.winv, qb.ts));     // :377
     } else {
     CHK(udt_factor(h, h->Tr, h->Dr, nullptr, 0, qb));                  // :376
-    if (ov) CHK(aux_begin(h));
-    CHK(rdivp_set(h, h->Ur, h->Tr, h->Ur, qb, ov ? winv_x : qb.winv, ov ? ts_x : qb.ts));  // :377
-    if (ov) aux_end(h);
+    CHK(rdivp_set(h, h->Ur, h->Tr, h->Ur, qb, qb.winv, qb.ts));        // :377
     CHK(udt_formq(h, h->Ul, qb, qb.winv, qb.ts));
     }
-    CHK(aux_join(h));                                                  // (the next product overwrites Tr = T of :376)
     CHK(run_gemm(h, gemm_base(h, U_(h, h->Tl), 0, U_(h, h->Ul), 0, h->Tr)));  // :378
     g = gemm_base(h, U_(h, h->Ur), 0, U_(h, h->Tr), 1, out);           // :382-391
     g.kscale = vs_inv(h->Dr, n);
@@ -581,11 +522,7 @@ static int run_slab(dqmc_handle *h, const SlabArgs &a)
 // ---- slice sequences (stack.jl:272-311, slice_matrices.jl:42-76) -------------------
 // The s products of a stack interval only need the HS field of slices that sweep_spatial has already left behind, in
 // the order the sweep visits them (up pass: B_l X for l = (idx-1)s+1 .. idx s; down pass: B_l' X for l = idx s ..
-// (idx-1)s+1).  In overlap mode every sweep_spatial therefore advances the chain of the current interval by one
-// product on the auxiliary stream (chain_advance), and the stabilisation step only has the last product (with the
-// Diagonal(D) column scaling of stack.jl:281 / :305) left.  Same kernel, same operand order: bit-identical to the
-// s-step launch.  A chain that does not match the interval (first pass after prepare, a slice swept twice, HS field
-// set from outside) is dropped and the interval is multiplied out in one launch as before.
+// (idx-1)s+1).
 static const int8_t *conf_slice(dqmc_handle *h, int slice) { return h->conf + (long)(slice - 1) * h->N; }
 static void chain_steps(dqmc_handle *h, SlabArgs &a, int dir, int idx, int t0, int t1)  // products t0 .. t1 - 1
 {
@@ -602,52 +539,17 @@ static void chain_steps(dqmc_handle *h, SlabArgs &a, int dir, int idx, int t0, i
         }
     }
 }
-static bool chain_ahead_ok(dqmc_handle *h)
-{
-    return h->overlap && h->chain.buf[0] && h->slab && !h->cb.on && h->s >= 2 && h->s <= SLAB_MAX_STEPS;
-}
-// called at the end of sweep_spatial at slice l
-static int chain_advance(dqmc_handle *h, int l)
-{
-    auto &c = h->chain;
-    if (!chain_ahead_ok(h) || (h->direction != 1 && h->direction != -1)) { c.valid = false; return 0; }
-    const int dir = h->direction, idx = (l - 1) / h->s + 1;
-    const int t = dir == 1 ? (l - 1) % h->s : idx * h->s - l;
-    if (t == 0) { c.valid = true; c.dir = dir; c.idx = idx; c.next_t = 0; }
-    else if (!(c.valid && c.dir == dir && c.idx == idx && c.next_t == t)) { c.valid = false; return 0; }
-    if (t >= h->s - 1) return 0;  // the last product belongs to the stabilisation step
-    const double *X = t == 0 ? (dir == 1 ? uslot(h, idx - 1) : uslot(h, idx)) : c.out;
-    double *out = c.buf[t & 1];
-    SlabArgs a = slab_base(h, X, h->nn, 0, out);
-    chain_steps(h, a, dir, idx, t, t + 1);
-    CHK(aux_begin(h));
-    const int rc = run_slab(h, a);
-    aux_end(h);
-    CHK(rc);
-    c.out = out;
-    c.next_t = t + 1;
-    return 0;
-}
 static int wrap_greens_slab(dqmc_handle *h, const double *src, double *dst, int curr_slice, int direction);
 // dir = +1: add_slice_sequence_left(idx), reads slot idx - 1, writes slot idx; dir = -1: add_slice_sequence_right(idx),
 // reads slot idx, writes slot idx - 1 (idx 1-based as in the reference).  wrap_temp: the up pass's wrap of the old
-// Green's function for the propagation check (stack.jl:534-536) rides on the auxiliary stream.
+// Green's function for the propagation check (stack.jl:534-536).
 static int add_slice_sequence(dqmc_handle *h, int dir, int idx, bool wrap_temp)
 {
     const int src = dir == 1 ? idx - 1 : idx, dst = dir == 1 ? idx : idx - 1;
-    CHK(aux_join(h));  // chain products of this interval; a Q still being formed for the slot read below
-    auto &c = h->chain;
-    int t0 = 0;
+    const int t0 = 0;
     const double *X = uslot(h, src);
-    if (c.valid && chain_ahead_ok(h) && c.dir == dir && c.idx == idx && c.next_t >= 1) { X = c.out; t0 = c.next_t; }
-    c.valid = false;
     if (wrap_temp) {
-        if (h->slab && !h->cb.on) {
-            CHK(aux_begin(h));
-            const int rc = wrap_greens_slab(h, h->greens, h->greens_temp, h->current_slice - 1, 1);
-            aux_end(h);
-            CHK(rc);
-        }
+        if (h->slab && !h->cb.on) CHK(wrap_greens_slab(h, h->greens, h->greens_temp, h->current_slice - 1, 1));
     }
     double *out = nullptr;
     if (h->slab && !h->cb.on && h->s <= SLAB_MAX_STEPS) {  // the (remaining) products in one launch
@@ -672,17 +574,13 @@ static int add_slice_sequence(dqmc_handle *h, int dir, int idx, bool wrap_temp)
         CHK(run_gemm(h, g));
         X = out;
     }
-    // new factors into the spare, then slot dst <-> spare: the old slot dst stays readable.  The Q of the new slot is
-    // not needed before the second product of calculate_greens_AVX!: it is formed on the auxiliary stream
+    // new factors into the spare, then slot dst <-> spare: the old slot dst stays readable
     const int sp = h->K + 1;
     if (udt_is_fused(h, 0)) {
         CHK(udt_fused(h, out, uslot(h, sp), dslot(h, sp), h->tmp2, 1, h->qs[0]));
     } else {
         CHK(udt_factor(h, out, dslot(h, sp), h->tmp2, 1, h->qs[0]));
-        CHK(aux_begin(h));
-        const int rc = udt_formq(h, uslot(h, sp), h->qs[0], h->qs[0].winv, h->qs[0].ts);
-        aux_end(h);
-        CHK(rc);
+        CHK(udt_formq(h, uslot(h, sp), h->qs[0], h->qs[0].winv, h->qs[0].ts));
     }
     CHK(run_gemm(h, gemm_base(h, U_(h, h->tmp2), 0, U_(h, tslot(h, src)), 0, tslot(h, sp))));
     slot_swap_spare(h, dst);
@@ -781,7 +679,6 @@ static int init_stack(dqmc_handle *h)
 // stack.jl:242-255
 static int build_stack(dqmc_handle *h)
 {
-    h->chain.valid = false;
     CHK(reset_slot(h, 0));
     for (int i = 1; i <= h->K; ++i) CHK(add_slice_sequence_left(h, i));
     h->current_slice = h->M + 1;
@@ -804,9 +701,8 @@ static int propagate(dqmc_handle *h)
                 const int idx = (h->current_slice - 1) / s;
                 const Udt R = slot_ref(h, idx);
                 // stack.jl:534-536 wraps greens_temp unconditionally; its result is only observable through the
-                // check, so the wrap is skipped when the check is off.  (Slab form: out of place next to the
-                // slice sequence, on the auxiliary stream; it is awaited inside calculate_greens_src before
-                // anything overwrites mc.s.greens... which the first product there does: hence the join below.)
+                // check, so the wrap is skipped when the check is off.  (Slab form: out of place, in front of the
+                // slice sequence.)
                 const bool wt = h->p.check_propagation_error != 0, wt_slab = wt && h->slab && !h->cb.on;
                 CHK(add_slice_sequence_left(h, idx, wt_slab));
                 const Udt L = slot_ref(h, idx);
@@ -873,7 +769,7 @@ static int sweep_spatial(dqmc_handle *h)
     const int l = h->current_slice;
     if (l < 1 || l > h->M) return fail(h, DQMC_ERR_STATE, "sweep_spatial: current_slice outside 1..slices");
     CHK(sweep_spatial_launches(h));
-    return chain_advance(h, l);  // this slice's HS field is final for the current pass: next product of its interval
+    return 0;
 }
 static int sweep_spatial_launches(dqmc_handle *h)
 {
@@ -886,18 +782,6 @@ static int sweep_spatial_launches(dqmc_handle *h)
         const size_t istr = (size_t)h->units * sweep_lu_image_doubles();
         const long cstr = (long)h->N * h->M;
         hipEvent_t a, b;
-        if (h->sweep_persist) {
-            // the whole slice in one launch: chunks back to back, tagged hand-overs between the elimination and the
-            // flush workgroups (sweep_lu.hip)
-            timing_events(h, &a, &b);
-            h->slice_launch += 1;
-            HIPCHK(launch_sweep_slice(h->n, h->nb, h->W, h->greens, h->greens_alt, h->nn, cslice, cstr, h->lu_img, (long)istr,
-                                      h->sc, h->rng, h->stats, h->p.check_sign_problem, h->qr_ws.errflag, h->slice_flags,
-                                      h->slice_launch, h->cur, a, b));
-            CHK(timing_push(h, a, b, DQMC_K_SWEEP));
-            if ((h->n / 64) & 1) std::swap(h->greens, h->greens_alt);
-            return 0;
-        }
         if (h->sweep_fused && h->n % 64 == 0 && h->N >= 128) {
             // the elimination of chunk c runs beside the flush of chunk c - 1 (one launch per chunk boundary)
             const int nc = h->N / 64;
@@ -988,6 +872,7 @@ int dqmc_create(const dqmc_params *p, dqmc_handle **out)
 {
     if (!p || !out) return fail(nullptr, DQMC_ERR_INVALID, "dqmc_create: null argument");
     *out = nullptr;
+    refresh_kernel_switches();  // (the launchers' A/B switches: read here, never inside a launch)
     if (p->n_sites < 1 || p->slices < 1 || p->safe_mult < 1 || p->n_walkers < 1)
         return fail(nullptr, DQMC_ERR_INVALID, "dqmc_create: n_sites, slices, safe_mult, n_walkers must be >= 1");
     if (p->slices % p->safe_mult != 0)  // stack.jl:115: convert(Int, slices / safe_mult) throws InexactError
@@ -1106,47 +991,11 @@ int dqmc_create(const dqmc_params *p, dqmc_handle **out)
     CCHK(dalloc(h, &h->trsm_w, wn));
     if (h->n > 256) CCHK(dalloc(h, &h->trsm_s, un));
     CCHK(dalloc(h, &h->pivot, uv));
-    // DQMC_OVERLAP=1: independent kernels of a stabilisation step side by side on a second stream (the Q formation of a
-    // new stack slot and the up pass's wrap of the old Green's function next to the following factorisation).
-    // Measured at config 3 (gpurun_out/r03_overlap2.log): 70.0 against 70.3 ms per sweep - every
-    // kernel here holds most of a CU's LDS or registers, so two of them hardly ever share a CU, and each cross-stream
-    // dependency costs ~6 us on the main stream.  Off by default: one stream, one launch order.
-    if (getenv("DQMC_OVERLAP")) {
-        CHIP(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
-        CHIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-        CHIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
-        auto &q = h->qs[1];
-        CCHK(dalloc(h, &q.V, un)); CCHK(dalloc(h, &q.W, un)); CCHK(dalloc(h, &q.S, un));
-        CCHK(dalloc(h, &q.tau, uv)); CCHK(dalloc(h, &q.pivot, uv)); CCHK(dalloc(h, &q.winv, wn));
-        CCHK(dalloc(h, &h->aux_winv, wn));
-        if (h->n > 256) { CCHK(dalloc(h, &q.ts, un)); CCHK(dalloc(h, &h->aux_ts, un)); }
-        h->overlap_rdivp = getenv("DQMC_OVERLAP_RDIVP") != nullptr;
-        // look-ahead chain products (one per sweep_spatial, DQMC_CHAIN_AHEAD): measured slower - the slab kernels'
-        // 132 KB of LDS keep the product from sharing CUs with the wrap, so it delays the next elimination instead
-        if (h->slab && getenv("DQMC_CHAIN_AHEAD")) {
-            CCHK(dalloc(h, &h->chain.buf[0], un));
-            CCHK(dalloc(h, &h->chain.buf[1], un));
-        }
-        h->overlap = true;
-    }
     CCHK(alloc_qr_workspace(h));
     CCHK(dalloc(h, &h->sU, (size_t)h->units * h->n * h->kd));
     CCHK(dalloc(h, &h->sVT, (size_t)h->units * h->n * h->kd));
     CCHK(dalloc(h, &h->greens_alt, un));
     CCHK(dalloc(h, &h->lu_img, 2 * (size_t)h->units * sweep_lu_image_doubles()));
-    // DQMC_SWEEP_PERSIST=1: one launch per time slice (sweep_slice_kernel: the elimination workgroup runs its chunks back
-    // to back, tagged hand-overs to and from the flush workgroups).  Built and parity-tested in round 3, measured at
-    // config 3: 143.9 us per slice against 137 us for the five launches it replaces (with memory-model fences: 214 us) -
-    // in-kernel stamps show the same 8.5 us from the start of a chunk to its first decision as in the launch-per-chunk
-    // form (that time is instruction issue and L2 latency of the prologue, not the HBM misses behind a kernel boundary),
-    // so the launch gaps it saves are smaller than the hand-overs it adds.  Off by default.
-    {
-        const char *e = getenv("DQMC_SWEEP_PERSIST");
-        if (h->sweep_lu && h->sweep_fused && h->n % 256 == 0 && h->n <= 512 && e && atoi(e) != 0) {
-            CCHK(dalloc(h, &h->slice_flags, sweep_slice_flag_words(h->W, h->units)));
-            h->sweep_persist = true;
-        }
-    }
     CCHK(dalloc(h, &h->rng, (size_t)h->W));
     CCHK(dalloc(h, &h->stats, (size_t)h->W));
     CCHK(dalloc(h, &h->pc_scratch, 2 * (size_t)h->W));
@@ -1185,9 +1034,6 @@ int dqmc_destroy(dqmc_handle *h)
     for (void *q : h->allocs) (void)hipFree(q);
     for (double *u : h->uniforms)
         if (u) (void)hipFree(u);
-    if (h->aux) { (void)hipStreamSynchronize(h->aux); (void)hipStreamDestroy(h->aux); }
-    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     ut_free(h);
     delete h;
@@ -1206,11 +1052,9 @@ int dqmc_set_conf(dqmc_handle *h, int32_t w, const int8_t *conf)
     const size_t sz = (size_t)h->N * h->M;
     for (size_t i = 0; i < sz; ++i)
         if (conf[i] != 1 && conf[i] != -1) return fail(h, DQMC_ERR_INVALID, "conf entries must be +1 or -1");
-    if (h->aux) HIPCHK(hipStreamSynchronize(h->aux));
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(h->conf + (size_t)w * sz, conf, sz, hipMemcpyHostToDevice));
     h->conf_version++;
-    h->chain.valid = false;
     return DQMC_OK;
 }
 int dqmc_get_conf(dqmc_handle *h, int32_t w, int8_t *conf)
@@ -1268,10 +1112,6 @@ static int check_rng(dqmc_handle *h)
 int dqmc_synchronize(dqmc_handle *h)
 {
     ENTER(h);
-    if (h->aux) {
-        HIPCHK(hipStreamSynchronize(h->aux));
-        h->aux_pending = false;
-    }
     HIPCHK(hipStreamSynchronize(h->stream));
     CHK(timing_drain(h));
     CHK(check_qr_workspace(h));
@@ -1347,7 +1187,6 @@ int dqmc_get_greens_eff(dqmc_handle *h, int32_t w, double *out)
 int dqmc_set_greens_eff(dqmc_handle *h, int32_t w, const double *in)
 {
     ENTER(h); WALKER_OK(h, w);
-    if (h->aux) HIPCHK(hipStreamSynchronize(h->aux));
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(h->greens + (size_t)w * h->nb * h->nn, in, sizeof(double) * h->nb * h->nn, hipMemcpyHostToDevice));
     return DQMC_OK;
@@ -1470,7 +1309,6 @@ int dqmc_set_conf_bits(dqmc_handle *h, int32_t w, const uint64_t *chunks)
     ENTER(h); WALKER_OK(h, w);
     const size_t sz = (size_t)h->N * h->M, nch = (sz + 63) / 64;
     unsigned long long *d = nullptr;
-    if (h->aux) HIPCHK(hipStreamSynchronize(h->aux));
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMalloc((void **)&d, nch * sizeof(unsigned long long)));
     hipError_t e1 = hipMemcpy(d, chunks, nch * sizeof(unsigned long long), hipMemcpyHostToDevice);
@@ -1479,7 +1317,6 @@ int dqmc_set_conf_bits(dqmc_handle *h, int32_t w, const uint64_t *chunks)
     (void)hipFree(d);
     HIPCHK(e3);
     h->conf_version++;
-    h->chain.valid = false;
     return DQMC_OK;
 }
 
@@ -1927,6 +1764,7 @@ static int scratch_init(dqmc_handle *h, int device_id, int n, int batch)
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(nullptr, DQMC_ERR_NO_DEVICE, "no HIP device visible");
     if (device_id < 0 || device_id >= ndev) return fail(nullptr, DQMC_ERR_INVALID, "device_id out of range");
     if (n < 1 || n > 1024 || batch < 1) return fail(nullptr, DQMC_ERR_INVALID, "n must be 1..1024 and batch >= 1");
+    refresh_kernel_switches();
     h->p.device_id = device_id;
     h->n = h->N = n;
     h->nb = 1;

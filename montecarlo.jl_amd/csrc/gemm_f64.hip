@@ -275,7 +275,7 @@ hipError_t launch_gemm(const GemmArgs &g, hipStream_t s, hipEvent_t start, hipEv
     const int tm = (g.M + BM - 1) / BM, tn = (g.N + BN - 1) / BN;
     const int groups = (g.n_units + 7) / 8;
     dim3 grid(groups * 8 * tm * tn), block(256);
-    static const int stagger = getenv("DQMC_GEMM_STAGGER") ? atoi(getenv("DQMC_GEMM_STAGGER")) : 0;
+    const int stagger = kernel_switches().gemm_stagger;
     const bool full = g.M % BM == 0 && g.N % BN == 0 && g.K % BK == 0;
 #define GEMM_LAUNCH4(TA, TB, FU, KS) \
     hipExtLaunchKernelGGL((gemm_kernel<TA, TB, FU, KS>), grid, block, 0, s, start, stop, 0, g, tm, tn, stagger)

@@ -105,8 +105,25 @@ hipError_t launch_gemm_flush(int n, int n_units, const double *U, const double *
 // column j of the factored matrix is original column pivot[j]).
 // Workspace of the cooperative (8 workgroups per matrix) QR: mailbox of n_units x 2 x 8 slots of
 // QR_COOP_SLOT doubles (tagged packets), an error flag (bounded spins), a launch counter.
+// A/B and fallback switches of the launchers (environment).  They are read ONCE per handle / primitive call
+// (refresh_kernel_switches(), called when a handle is set up), never inside a launch: no environ scan per stabilisation step,
+// no change of kernels or numerics in the middle of a run, no race with a host thread that edits the environment.
+struct KernelSwitches {
+    bool qr_stream = false;       // DQMC_QR_STREAM: streaming single-workgroup QR instead of the tile kernel
+    bool qr_tile_bounds = false;  // DQMC_QR_TILE_BOUNDS: tile QR with run-time bounds at n == 256
+    bool qr_nopanel = false;      // DQMC_QR_NOPANEL: streaming QR instead of the panel kernel for n > 256
+    double qp_thr = 1e-4;         // DQMC_QP_THR: recompute threshold of the panel kernel's down-dated norms
+    bool trsm_simple = false;     // DQMC_TRSM_SIMPLE: substitution kernel (the fallback of the MFMA solves)
+    bool trsm_ll = false;         // DQMC_TRSM_LL: left-looking slab-in-LDS solve (n > 256 panels)
+    bool trsm_bounds = false;     // DQMC_TRSM_BOUNDS: right-looking solve with run-time bounds at n == 256
+    bool flush_ncp2 = false;      // DQMC_FLUSH_NCP2: two column passes per flush workgroup
+    int gemm_stagger = 0;         // DQMC_GEMM_STAGGER
+};
+const KernelSwitches &kernel_switches();
+void refresh_kernel_switches();
+
 constexpr int QR_COOP_SLOT = 528;  // 264 packets of 16 bytes
-constexpr int QR_COOP_SLOTS_PER_UNIT = 24;  // 2 parities x 8 parts (qr_coop_kernel) or 2 x 4 parts x 3 kinds (qr_rows_kernel)
+constexpr int QR_COOP_SLOTS_PER_UNIT = 16;  // 2 parities x 8 parts (qr_coop_kernel)
 struct QrCoopWorkspace {
     double *mailbox = nullptr;
     int *errflag = nullptr;
@@ -117,7 +134,6 @@ struct QrCoopWorkspace {
     // A/B and test switches, read from the environment when the workspace is set up (per handle / per primitive call):
     int force_sc1 = 0;      // DQMC_QR_SC1: write-through (agent-scope) packet stores regardless of placement
     int no_coop = 0;        // DQMC_QR_NOCOOP: single-workgroup kernels only
-    int rows = 0;           // DQMC_QR_ROWS: n == 256 two-phase form with the row-split first phase (qr_rows_kernel)
     int force_timeout = 0;  // DQMC_QR_FORCE_TIMEOUT: 1 = every cooperative launch gives up at once;
                             // "step:<j>" -> 2 + j: part 3 of every matrix stops publishing at step j (bounded spins run out)
     // pre-pivoted blocked UDT (qrb.hip, n == 256): its own mailbox; blk_max_blocks = co-resident workgroups (0 = off)
@@ -140,7 +156,6 @@ hipError_t launch_qr_pivot(int n, int n_units, double *A, long strideA, double *
                            QrCoopWorkspace *ws, double *W, long strideW, const double **factored, hipStream_t s,
                            double *X = nullptr, long strideX = 0);
 int qr_coop_blocks_per_cu();
-int qr_rows_blocks_per_cu();
 
 // After launch_qr_pivot: D = |diag R| (UDT.jl:268-272); V = unit-lower Householder
 // vectors (n x n, explicit zeros/ones); T = D^-1 R:
@@ -233,14 +248,7 @@ hipError_t launch_sweep_fused(int n, int nb, int n_walkers, const double *Gin, d
                               int8_t *conf_slice, long conf_stride, int site0, int site0p, double *img,
                               const double *imgp, SweepConsts sc, WalkerRng *rng, DevStats *stats, int check_sign,
                               int *errflag, hipStream_t s, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
-// the whole site sweep of one time slice in ONE launch (n % 256 == 0; the grid - n_walkers + 4 n_units workgroups at
-// n = 256 - must be co-resident): chunks back to back with tagged hand-overs between the elimination and the flush
-// workgroups; the result is in G0 (n / 64 even) or G1
-size_t sweep_slice_flag_words(int n_walkers, int n_units);
-hipError_t launch_sweep_slice(int n, int nb, int n_walkers, double *G0, double *G1, long strideG, int8_t *conf_slice,
-                              long conf_stride, double *img, long istr, SweepConsts sc, WalkerRng *rng, DevStats *stats,
-                              int check_sign, int *errflag, unsigned *flags, unsigned launch, hipStream_t s,
-                              hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
+
 hipError_t launch_sweep_flush_lu(int n, int n_units, const double *Gin, double *Gout, long strideG, int site0,
                                  int nsites, const double *img, hipStream_t s, hipEvent_t start = nullptr,
                                  hipEvent_t stop = nullptr);

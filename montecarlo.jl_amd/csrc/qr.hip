@@ -1263,356 +1263,9 @@ __global__ __launch_bounds__(256) void qr_coop_kernel(int n, int n_units, double
     }
 }
 
-// ---------------------------------------------------------------------------
-// Row-split cooperative variant for the first steps at n == 256 (round 3, DQMC_QR_ROWS=1): FOUR workgroups per matrix,
-// workgroup p keeps ROWS 64 p .. 64 p + 63 of ALL 256 columns in registers, one column per thread (64 doubles).  What
-// this changes against qr_coop_kernel (eight workgroups, 32 columns each):
-//   * a reflector is applied with NO reduction inside the workgroup - a thread's partial dot product over its 64 rows is
-//     one value, the four partial values of a column meet through the mailbox - and the pivot column never travels:
-//     every workgroup already holds its rows of it;
-//   * ONE hand-off per step instead of two: the packet of column c carries the partial dot, the owner of row j adds that
-//     row's entries, the header the partial squared norm of the pivot column (so the reflector is built from a norm
-//     taken from scratch, as in the reference) and its element j;
-//   * which needs the norms that SELECT the pivot without a second hand-off: they are down-dated with row j of R
-//     (|a_c|^2 -= r_jc^2, identical arithmetic in all four workgroups, so they agree bit for bit) and recomputed
-//     from scratch - one extra hand-off, all columns - whenever one of them has lost four digits since it was last
-//     exact (same rule as qr_panel_kernel; the only place where the pivot choice can differ from the reference's: near-ties
-//     within ~1e-9).
-// Logical pivoting, position tables, tags, parity double buffering, bounded spins, fallback word and hand-over format
-// (live columns to X by original column id, position table to piv) as in qr_coop_kernel: qr_tail_kernel continues.
 #ifdef QB_STAMPS
 __device__ long long *qb_stamp_ptr = nullptr;  // [wave 8][step 192][point 8] of unit 0 (diagnostic build only)
-#define QRW_STAMP(P)                                                                                     \
-    if (blockIdx.x == (unsigned)QRW_STAMP_BLOCK && lane == 0 && qb_stamp_ptr)                            \
-        qb_stamp_ptr[(w * 192 + j) * 8 + (P)] = __builtin_amdgcn_s_memtime();
-#ifndef QRW_STAMP_BLOCK
-#define QRW_STAMP_BLOCK 0
 #endif
-#else
-#define QRW_STAMP(P)
-#endif
-constexpr int QRW_PARTS = 4;
-constexpr int QRW_KINDS = 3;  // packet kinds per part and parity: partial dots, row j, partial norms of a recompute round
-__device__ __forceinline__ qc_word *qrw_slot(qc_word *mb_unit, int par, int part, int kind)
-{
-    return mb_unit + ((long)((par * QRW_PARTS + part) * QRW_KINDS + kind)) * QC_MB * 2;
-}
-// K packets at once: all loads are in flight together (one trip to the L2 per attempt, not K), then the tags are checked
-template <int K>
-__device__ __forceinline__ bool qc_get_many(const qc_word *const (&slot)[K], unsigned tag, double (&v)[K])
-{
-    for (unsigned spins = 0; spins < QC_SPIN_LIMIT; ++spins) {
-        unsigned long long a[K], b[K];
-#pragma unroll
-        for (int i = 0; i < K; ++i) {
-            a[i] = __hip_atomic_load(slot[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            b[i] = __hip_atomic_load(slot[i] + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        bool ok = true;
-#pragma unroll
-        for (int i = 0; i < K; ++i) ok = ok && (unsigned)(a[i] >> 32) == tag && (unsigned)(b[i] >> 32) == tag;
-        if (ok) {
-#pragma unroll
-            for (int i = 0; i < K; ++i) v[i] = __longlong_as_double((long long)((a[i] & 0xffffffffull) | (b[i] << 32)));
-            return true;
-        }
-        __builtin_amdgcn_s_sleep(1);
-    }
-    return false;
-}
-// LR = local index (0..63) of the first row of the 8-row region that contains row j in the workgroup that owns it;
-// -1: this workgroup does not own row j (all of its rows are live, or all are finished)
-template <int LR>
-__device__ __forceinline__ double qrw_pick(const double (&x)[64], int lj)
-{
-    if (LR < 0) return 0.0;
-    // as a sum with 0/1 coefficients: a chain of selects is turned into an indexed load by the compiler, which would put
-    // x into scratch memory (entries are finite: a NaN/Inf matrix is caught by the engine's checks either way)
-    double v = 0.0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v = __builtin_fma((lj - (LR < 0 ? 0 : LR) == i) ? 1.0 : 0.0, x[(LR < 0 ? 0 : LR) + i], v);
-    return v;
-}
-__global__ __launch_bounds__(256) void qr_rows_kernel(int n_units, const double *__restrict__ Aall, long strideA,
-                                                     double *__restrict__ tauall, int *__restrict__ pivall,
-                                                     double *mailbox, unsigned long long epoch, int *fb, int force_sc1,
-                                                     double *__restrict__ Wall, long strideW, int force_timeout,
-                                                     int nsteps, double *__restrict__ Xall, long strideX)
-{
-    constexpr int n = 256;
-    __shared__ __attribute__((aligned(16))) double ubuf[2][4][64];   // [step parity][wave]: that wave's candidate column (my rows)
-    __shared__ __attribute__((aligned(16))) double wc[2][4][2];      // [step parity][wave]: {norm, bits(pos | col << 32)}
-    __shared__ int s_abort, s_flag[2], s_cj[2];
-    __shared__ int xcc_seen[QRW_PARTS];
-
-    const int bid = blockIdx.x, xcd = bid & 7, seq = bid >> 3;
-    const int unit = (seq / QRW_PARTS) * 8 + xcd, part = seq % QRW_PARTS;
-    if (unit >= n_units) return;
-    const double *__restrict__ A = Aall + (long)unit * strideA;
-    double *__restrict__ Wo = Wall + (long)unit * strideW;
-    double *__restrict__ tau = tauall + (long)unit * n;
-    int *__restrict__ piv = pivall + (long)unit * n;
-    qc_word *mb_unit = reinterpret_cast<qc_word *>(mailbox) + (long)unit * 2 * QRW_PARTS * QRW_KINDS * QC_MB * 2;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int c = tid;  // my original column
-    const int row0 = 64 * part;
-    double x[64];
-#pragma unroll
-    for (int l = 0; l < 64; ++l) x[l] = A[row0 + l + (long)n * c];
-    int mypos = c;
-    if (force_timeout == 1) {  // test hook: give up at once (the guarded kernel behind the launch takes over)
-        if (tid == 0) atomicExch(&fb[0], (int)(epoch & 0x7fffffffull));
-        return;
-    }
-    if (tid == 0) { s_abort = 0; s_flag[0] = s_flag[1] = 0; }
-    __syncthreads();
-    // ---- placement check + initial norms (one exchange with the launch's base tag)
-    const unsigned tag0 = (unsigned)(epoch * 1024ull);
-    bool same_xcd = true;
-    double nrm, nref;
-    {
-        double pn = 0.0;
-#pragma unroll
-        for (int l = 0; l < 64; ++l) pn = __builtin_fma(x[l], x[l], pn);
-        qc_word *mine = qrw_slot(mb_unit, 0, part, 2);
-        qc_put(mine + 2 * tid, pn, tag0, tag0);
-        if (tid == 0) {
-            const unsigned my_xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 0xfu;
-            qc_put(mine + 2 * 260, (double)my_xcc, tag0, tag0);
-        }
-        {   // (own slot -> a partner's: nothing of mine is read back; the own value is put in below)
-            const qc_word *sl[QRW_PARTS];
-            double got[QRW_PARTS];
-#pragma unroll
-            for (int q = 0; q < QRW_PARTS; ++q) sl[q] = qrw_slot(mb_unit, 0, q == part ? (part + 1) & 3 : q, 2) + 2 * tid;
-            if (!qc_get_many<QRW_PARTS>(sl, tag0, got)) s_abort = 1;
-            double tot = 0.0;
-#pragma unroll
-            for (int q = 0; q < QRW_PARTS; ++q) tot += (q == part) ? pn : got[q];  // same order in all four workgroups
-            nrm = nref = tot;
-        }
-        if (tid < QRW_PARTS) {
-            double v = -1.0;
-            unsigned hw;
-            if (!qc_get(qrw_slot(mb_unit, 0, tid, 2) + 2 * 260, tag0, tag0, 0xffffffffu, v, hw)) s_abort = 1;
-            xcc_seen[tid] = (int)v;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int q = 1; q < QRW_PARTS; ++q) same_xcd = same_xcd && xcc_seen[q] == xcc_seen[0];
-        if (force_sc1) same_xcd = false;
-    }
-    auto put = [&](qc_word *slot, double v, unsigned tag) {
-        if (same_xcd) qc_put_local(slot, v, tag, tag);
-        else qc_put(slot, v, tag, tag);
-    };
-
-#define QRW_STEP_BODY(LR)                                                                                              \
-    {                                                                                                                  \
-        /* partial dot of my column with the pivot column over my live rows; my part of the pivot column's norm */    \
-        const double2 *u2 = reinterpret_cast<const double2 *>(ub);                                                      \
-        double d0 = 0.0, d1 = 0.0;                                                                                     \
-        if (part > pj) {                                                                                               \
-            _Pragma("unroll") for (int l = 0; l < 64; l += 2) {                                                       \
-                const double2 uu = u2[l >> 1];                                                                         \
-                d0 = __builtin_fma(uu.x, x[l], d0);                                                                    \
-                d1 = __builtin_fma(uu.y, x[l + 1], d1);                                                                \
-            }                                                                                                          \
-        } else if (part == pj) {                                                                                       \
-            _Pragma("unroll") for (int l = ((LR) < 0 ? 0 : (LR)); l < 64; l += 2) {                                   \
-                const double2 uu = u2[l >> 1];                                                                         \
-                d0 = __builtin_fma((l > lj) ? uu.x : 0.0, x[l], d0);                                                   \
-                d1 = __builtin_fma((l + 1 > lj) ? uu.y : 0.0, x[l + 1], d1);                                           \
-            }                                                                                                          \
-        }                                                                                                              \
-        sdot = d0 + d1;                                                                                                \
-        xjc = qrw_pick<(LR)>(x, lj);                                                                                   \
-    }
-
-    for (int j = 0; j < nsteps; ++j) {
-        const int par = j & 1;
-        const unsigned tag = (unsigned)(epoch * 1024ull + (unsigned long long)j + 1ull);
-        const int pj = j >> 6, lj = j & 63;
-        // test hook (DQMC_QR_FORCE_TIMEOUT=step:<j>): part 3 drops out, its partners run out of spins
-        if (force_timeout >= 2 && part == 3 && j == force_timeout - 2) return;
-        QRW_STAMP(0)
-        // ---- a recompute round first, if the previous step flagged a column (identical decision in all workgroups)
-        // and the candidates of the waves (each wave leaves its candidate's rows in LDS before the barrier)
-        for (int round = 0; round < 2; ++round) {
-            const bool live = mypos >= j;
-            const double bn = wave_max_f64<1>(live ? nrm : -1.0);
-            const unsigned mp = live ? (unsigned)mypos : 0xffffffffu;
-            const unsigned bp = wave_min_u32<1>((live && nrm == bn) ? mp : 0xffffffffu);
-            const unsigned long long m = __ballot(live && mp == bp);
-            const int bl = m ? __ffsll((long long)m) - 1 : 0;
-            if (m && lane == bl) {
-                double2 *dst = reinterpret_cast<double2 *>(ubuf[par][w]);
-#pragma unroll
-                for (int l = 0; l < 64; l += 2) dst[l >> 1] = make_double2(x[l], x[l + 1]);
-            }
-            if (mypos == j) s_cj[par] = c;  // the column now at position j (trades places with the pivot)
-            if (lane == 0) {
-                wc[par][w][0] = m ? bn : -1.0;
-                wc[par][w][1] = __longlong_as_double((long long)(bp & 0x7fffffffu) | ((long long)(unsigned)(64 * w + bl) << 32));
-            }
-            QC_BARRIER();
-            if (round == 1 || s_flag[par] == 0 || s_abort) break;
-            // recompute: partial squared norms of the (updated) live columns over my live rows -> exchange -> sum
-            {
-                const unsigned rtag = (unsigned)(epoch * 1024ull + 512ull + (unsigned long long)j);
-                double pn = 0.0;
-                if (part >= pj) {
-#pragma unroll
-                    for (int l = 0; l < 64; ++l) pn = __builtin_fma((part > pj || l >= lj) ? x[l] : 0.0, x[l], pn);
-                }
-                put(qrw_slot(mb_unit, par, part, 2) + 2 * tid, pn, rtag);
-                const qc_word *sl[QRW_PARTS];
-                double got[QRW_PARTS];
-#pragma unroll
-                for (int q = 0; q < QRW_PARTS; ++q) sl[q] = qrw_slot(mb_unit, par, q == part ? (part + 1) & 3 : q, 2) + 2 * tid;
-                if (!qc_get_many<QRW_PARTS>(sl, rtag, got)) s_abort = 1;
-                double tot = 0.0;
-#pragma unroll
-                for (int q = 0; q < QRW_PARTS; ++q) tot += (q == part) ? pn : got[q];
-                if (mypos >= j) { nrm = tot; nref = tot; }
-                QC_BARRIER();
-                if (tid == 0) s_flag[par] = 0;
-                QC_BARRIER();
-            }
-        }
-        if (s_abort) break;
-        QRW_STAMP(1)
-        const int cj = s_cj[par];
-        // ---- the step's pivot: largest norm, then smallest position (UDT.jl:151-168)
-        double maxn = -1.0;
-        int jm = 0x7fffffff, cm = -1;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const double2 cq = *reinterpret_cast<const double2 *>(wc[par][q]);
-            const long long pc = __double_as_longlong(cq.y);
-            const int qp = (int)(pc & 0x7fffffff), qc = (int)(pc >> 32);
-            const bool better = (cq.x > maxn) | ((cq.x == maxn) & (qp < jm));
-            maxn = better ? cq.x : maxn;
-            jm = better ? qp : jm;
-            cm = better ? qc : cm;
-        }
-        if (maxn < 0.0) { cm = cj; jm = j; }  // nothing live: cannot happen for j < n
-        const double *ub = ubuf[par][cm >> 6];  // my rows of the pivot column (raw)
-        // ---- partial dot, row-j entry, partial norm of the pivot column
-        double sdot = 0.0, xjc = 0.0;
-        if (part == pj) {
-            switch (lj >> 3) {
-            case 0: QRW_STEP_BODY(0) break;
-            case 1: QRW_STEP_BODY(8) break;
-            case 2: QRW_STEP_BODY(16) break;
-            case 3: QRW_STEP_BODY(24) break;
-            case 4: QRW_STEP_BODY(32) break;
-            case 5: QRW_STEP_BODY(40) break;
-            case 6: QRW_STEP_BODY(48) break;
-            default: QRW_STEP_BODY(56) break;
-            }
-        } else QRW_STEP_BODY(-1)
-        double npart;
-        {   // every wave for itself (lanes 0..63 <-> my 64 rows of the pivot column): no hand-over inside the workgroup
-            const double uu = ub[lane];
-            const bool rl = part > pj || (part == pj && lane > lj);
-            npart = wave_sum(rl ? uu * uu : 0.0);
-        }
-        QRW_STAMP(2)
-        // ---- publish: partial dots (everybody), row j (its owner), header
-        {
-            put(qrw_slot(mb_unit, par, part, 0) + 2 * tid, sdot, tag);
-            if (part == pj) put(qrw_slot(mb_unit, par, part, 1) + 2 * tid, xjc, tag);
-            if (tid == 0) {
-                put(qrw_slot(mb_unit, par, part, 0) + 2 * 256, npart, tag);
-                if (part == pj) put(qrw_slot(mb_unit, par, part, 0) + 2 * 258, ub[lj], tag);
-            }
-        }
-        // ---- collect: the other parts' partial dots of my column, row j, headers (fixed order of summation)
-        QRW_STAMP(3)
-        double stot = 0.0, ntot = 0.0, xjp;
-        {
-            const int other = (part + 1) & 3;  // stands in for my own slots: nothing of mine is read back
-            const qc_word *sl[2 * QRW_PARTS + 2];
-            double got[2 * QRW_PARTS + 2];
-#pragma unroll
-            for (int q = 0; q < QRW_PARTS; ++q) {
-                const qc_word *base = qrw_slot(mb_unit, par, q == part ? other : q, 0);
-                sl[q] = base + 2 * tid;
-                sl[QRW_PARTS + q] = base + 2 * 256;
-            }
-            sl[2 * QRW_PARTS] = part == pj ? sl[0] : qrw_slot(mb_unit, par, pj, 1) + 2 * tid;
-            sl[2 * QRW_PARTS + 1] = part == pj ? sl[QRW_PARTS] : qrw_slot(mb_unit, par, pj, 0) + 2 * 258;
-            if (!qc_get_many<2 * QRW_PARTS + 2>(sl, tag, got)) s_abort = 1;
-#pragma unroll
-            for (int q = 0; q < QRW_PARTS; ++q) {  // same order of summation in all four workgroups
-                stot += (q == part) ? sdot : got[q];
-                ntot += (q == part) ? npart : got[QRW_PARTS + q];
-            }
-            xjc = part == pj ? xjc : got[2 * QRW_PARTS];
-            xjp = part == pj ? ub[lj] : got[2 * QRW_PARTS + 1];
-        }
-        QRW_STAMP(4)
-        // ---- reflector scalars (UDT.jl:133-148); the norm is taken from scratch: element j and the four partial sums
-        const double maxval = __builtin_fma(xjp, xjp, ntot);
-        const bool nz = maxval != 0.0;
-        double rootn, rrootn;
-        qb_sqrt_rsqrt(nz ? maxval : 1.0, rootn, rrootn);
-        const double nu = nz ? copysign(rootn, xjp) : 1.0;
-        const double xi = nz ? xjp + nu : 1.0;
-        const double tj = nz ? __builtin_fma(fabs(xjp), rrootn, 1.0) : 0.0;  // xi / nu
-        const double rcp = qb_rcp(xi), trr = tj * rcp;
-        // u' x over all rows = xi x_jc + the four partial dots; H x = x - u (tj / xi^2) (u' x)
-        const double wv = ((__builtin_fma(xi, xjc, stot)) * rcp) * trr;
-        QRW_STAMP(5)
-        // ---- output column j (my rows of it), tau, position swap
-        if (tid < 64) {
-            const int r = row0 + tid;
-            const double uu = ub[tid];
-            Wo[r + (long)n * j] = (nz && r == j) ? -nu : ((nz && r > j) ? uu * rcp : uu);
-        }
-        if (c == cm) mypos = j;
-        else if (c == cj) mypos = jm;
-        if (tid == 0 && part == 0) tau[j] = tj;
-        // ---- apply H_j to my rows of my column if it is still live; row j of R; norm down-dating
-        if (mypos > j) {
-            const double2 *u2 = reinterpret_cast<const double2 *>(ub);
-            if (part > pj) {
-#pragma unroll
-                for (int l = 0; l < 64; l += 2) {
-                    const double2 uu = u2[l >> 1];
-                    x[l] = __builtin_fma(-uu.x, wv, x[l]);
-                    x[l + 1] = __builtin_fma(-uu.y, wv, x[l + 1]);
-                }
-            } else if (part == pj) {
-#pragma unroll
-                for (int l = 0; l < 64; l += 2) {
-                    const double2 uu = u2[l >> 1];
-                    x[l] = __builtin_fma((l > lj) ? -uu.x : ((l == lj) ? -xi : 0.0), wv, x[l]);
-                    x[l + 1] = __builtin_fma((l + 1 > lj) ? -uu.y : ((l + 1 == lj) ? -xi : 0.0), wv, x[l + 1]);
-                }
-            }
-            const double rjc = __builtin_fma(-xi, wv, xjc);
-            const double t = __builtin_fma(-rjc, rjc, nrm);
-            if (t <= 1e-4 * nref) s_flag[par ^ 1] = 1;  // cancellation: every norm is taken from scratch next step
-            nrm = t > 0.0 ? t : 0.0;
-        }
-        QRW_STAMP(6)
-    }
-#undef QRW_STEP_BODY
-    __syncthreads();
-    if (s_abort) {
-        if (tid == 0) atomicExch(&fb[0], (int)(epoch & 0x7fffffffull));
-        return;
-    }
-    if (part == 0) piv[mypos] = c;
-    // hand-over: my rows of the live columns go to X by ORIGINAL column id; qr_tail_kernel continues from there
-    if (nsteps < n && mypos >= nsteps) {
-        double *__restrict__ Xc = Xall + (long)unit * strideX + (long)n * c + row0;
-#pragma unroll
-        for (int l = 0; l < 64; ++l) Xc[l] = x[l];
-    }
-}
 
 // ---------------------------------------------------------------------------
 // Tail of the factorisation for n == 256.  After QB_J0 cooperative steps the trailing (256 - QB_J0)^2 block fits
@@ -2065,18 +1718,12 @@ int qr_coop_blocks_per_cu()
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, qr_coop_kernel, 256, 0) != hipSuccess) return 1;
     return nb < 1 ? 1 : (nb > 2 ? 2 : nb);
 }
-int qr_rows_blocks_per_cu()
-{
-    int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, qr_rows_kernel, 256, 0) != hipSuccess) return 0;
-    return nb;
-}
 
 static hipError_t launch_qr_single(int n, int n_units, double *A, long strideA, double *tau, int *pivot,
                                    const double *src, long strideSrc, int *guard, int guard_val, hipStream_t s,
                                    double *X = nullptr, long strideX = 0, const int *never = nullptr)
 {
-    const bool no_tile = getenv("DQMC_QR_STREAM") != nullptr;  // (A/B switches are read per launch: the tests toggle them)
+    const bool no_tile = kernel_switches().qr_stream;
     if (n > 128 && n <= 256 && !no_tile) {
         const size_t lds_t = (64 * QT_LSTRIDE + 3 * 256 + 8 * QT_VS + 8 * 256) * sizeof(double) + 256 * sizeof(int);
         int dev = 0;
@@ -2093,7 +1740,7 @@ static hipError_t launch_qr_single(int n, int n_units, double *A, long strideA, 
         // the first 128 steps, qr_tail_kernel the rest; `never` is a word that never equals -1 (the tail's exit test)
         const bool two_phase = X && never && n == 256 && !guard;
         const int nsteps = two_phase ? 128 : n;
-        if (n == 256 && !getenv("DQMC_QR_TILE_BOUNDS"))
+        if (n == 256 && !kernel_switches().qr_tile_bounds)
             hipLaunchKernelGGL(qr_tile256_kernel<true>, dim3(n_units), dim3(QT_THREADS), lds_t, s, n, nsteps, A, strideA, tau,
                                pivot, src, strideSrc, guard, guard_val, two_phase ? X : nullptr, strideX);
         else
@@ -2106,7 +1753,7 @@ static hipError_t launch_qr_single(int n, int n_units, double *A, long strideA, 
         return hipGetLastError();
     }
     // n > 256: the panel (dlaqps-style) kernel, unless it is switched off or its LDS does not fit
-    if (n > 256 && n <= 768 && !no_tile && !guard && !src && getenv("DQMC_QR_NOPANEL") == nullptr) {
+    if (n > 256 && n <= 768 && !no_tile && !guard && !src && !kernel_switches().qr_nopanel) {
         const size_t lds_p = ((size_t)(QP_NB + 4) * n + 2 * QP_NB + QP_WAVES + 2) * sizeof(double) + (size_t)(n + 2 + QP_WAVES) * sizeof(int);
         int dev = 0;
         (void)hipGetDevice(&dev);
@@ -2116,7 +1763,7 @@ static hipError_t launch_qr_single(int n, int n_units, double *A, long strideA, 
             (void)hipFuncSetAttribute((const void *)qr_panel_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
             pmask |= 1u << dev;
         }
-        const double thr = getenv("DQMC_QP_THR") ? atof(getenv("DQMC_QP_THR")) : 1e-4;      // recompute threshold (A/B)
+        const double thr = kernel_switches().qp_thr;  // recompute threshold (A/B)
         if (n <= 576) hipLaunchKernelGGL((qr_panel_kernel<9>), dim3(n_units), dim3(QP_THREADS), lds_p, s, n, A, strideA, tau, pivot, thr);
         else hipLaunchKernelGGL((qr_panel_kernel<12>), dim3(n_units), dim3(QP_THREADS), lds_p, s, n, A, strideA, tau, pivot, thr);
         return hipGetLastError();
@@ -2152,15 +1799,9 @@ hipError_t launch_qr_pivot(int n, int n_units, double *A, long strideA, double *
             // n == 256: the first steps cooperatively, the rest on one CU per matrix (qr_tail_kernel)
             const int tail_j0 = ws->tail_j0;  // DQMC_QR_TAIL at handle creation; default 128 x 128 tail
             const bool two_phase = n == 256 && X && (tail_j0 == 64 || tail_j0 == 96 || tail_j0 == 128);
-            // (the row-split kernel holds one workgroup per CU: max_blocks counts two of qr_coop_kernel's per CU at most)
-            if (two_phase && ws->rows && groups * 8 * QRW_PARTS * 2 <= ws->max_blocks)  // row-split variant: four workgroups per matrix (mailbox sized for it by the owner)
-                hipLaunchKernelGGL(qr_rows_kernel, dim3(groups * 8 * QRW_PARTS), dim3(256), 0, s, n_units, A, strideA, tau,
-                                   pivot, ws->mailbox, ws->epoch, ws->fb, force_sc1, W, strideW, force_to, tail_j0, X,
-                                   strideX);
-            else
-                hipLaunchKernelGGL(qr_coop_kernel, dim3(blocks), dim3(256), 0, s, n, n_units, A, strideA, tau, pivot,
-                                   ws->mailbox, ws->epoch, ws->fb, force_sc1, W, strideW, force_to, two_phase ? tail_j0 : n,
-                                   X, strideX);
+            hipLaunchKernelGGL(qr_coop_kernel, dim3(blocks), dim3(256), 0, s, n, n_units, A, strideA, tau, pivot,
+                               ws->mailbox, ws->epoch, ws->fb, force_sc1, W, strideW, force_to, two_phase ? tail_j0 : n,
+                               X, strideX);
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) return e;
             if (two_phase) {
@@ -2501,7 +2142,7 @@ hipError_t launch_trsm_right_upper(int n, int n_units, const double *A, long sA,
                                    const int *pivot, const double *dmul, long sV, double *Out, long sO,
                                    double *winv, hipStream_t s, double *scratch)
 {
-    const bool no_mfma = getenv("DQMC_TRSM_SIMPLE") != nullptr;
+    const bool no_mfma = kernel_switches().trsm_simple;
     const size_t lds_m = (256 * TM_XS + 16 * TM_TS + 16 * 18) * sizeof(double);
     auto set_attr = [&]() {
         int dev = 0;
@@ -2518,7 +2159,7 @@ hipError_t launch_trsm_right_upper(int n, int n_units, const double *A, long sA,
         hipLaunchKernelGGL(trsm_diag_inv_kernel, dim3(nblk, n_units), dim3(16), 0, s, n, T, sT, dmul, sV, winv, nblk);
         set_attr();
         // (in place is fine for both kernels: a workgroup reads all entries of its own 32 rows before it writes any)
-        const bool left_looking = getenv("DQMC_TRSM_LL") != nullptr;  // the slab-in-LDS kernel (A/B measurements)
+        const bool left_looking = kernel_switches().trsm_ll;  // the slab-in-LDS kernel (A/B measurements)
         if (left_looking)
             hipLaunchKernelGGL(trsm_mfma_kernel, dim3(n_units * slabs), dim3(128), lds_m, s, n, n, 0, n, nblk, A, sA, T, sT,
                                pivot, dmul, sV, Out, sO, slabs, winv);
@@ -2578,6 +2219,23 @@ hipError_t launch_trsm_right_upper(int n, int n_units, const double *A, long sA,
     else TR_LAUNCH(16);
 #undef TR_LAUNCH
     return hipGetLastError();
+}
+
+static KernelSwitches g_switches;
+const KernelSwitches &kernel_switches() { return g_switches; }
+void refresh_kernel_switches()
+{
+    KernelSwitches k;
+    k.qr_stream = getenv("DQMC_QR_STREAM") != nullptr;
+    k.qr_tile_bounds = getenv("DQMC_QR_TILE_BOUNDS") != nullptr;
+    k.qr_nopanel = getenv("DQMC_QR_NOPANEL") != nullptr;
+    if (const char *e = getenv("DQMC_QP_THR")) k.qp_thr = atof(e);
+    k.trsm_simple = getenv("DQMC_TRSM_SIMPLE") != nullptr;
+    k.trsm_ll = getenv("DQMC_TRSM_LL") != nullptr;
+    k.trsm_bounds = getenv("DQMC_TRSM_BOUNDS") != nullptr;
+    k.flush_ncp2 = getenv("DQMC_FLUSH_NCP2") != nullptr;
+    if (const char *e = getenv("DQMC_GEMM_STAGGER")) k.gemm_stagger = atoi(e);
+    g_switches = k;
 }
 
 }  // namespace dqmc

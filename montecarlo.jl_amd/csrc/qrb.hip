@@ -472,32 +472,21 @@ __device__ __forceinline__ void qrb_step(double (&x)[32], double (&r)[4], const 
             n1 = __builtin_fma(x[k + 1], x[k + 1], n1);
         }
         const double maxval = qsum8b(n0 + n1);
-        // UDT.jl:133-148 (a zero column gives NaN here where the reference gives tau = 0 and then 1 / D = Inf)
+        // UDT.jl:133-148, branch-free: a zero column keeps tau = 0 and stays as it is (D = 0, as in the reference)
+        const bool nz = maxval != 0.0;
         double rootn, rrootn;
-#ifdef QRB_T_NOSCAL
-        rootn = maxval; rrootn = maxval + 1.0;
-#else
-        q_sqrt_rsqrt(maxval, rootn, rrootn);
-#endif
-        const double nu = copysign(rootn, xi1);
-        const double xi = xi1 + nu;
-        const double tj = __builtin_fma(fabs(xi1), rrootn, 1.0);  // xi / nu
-#ifdef QRB_T_NOSCAL
-        const double beta = nu * xi;
-#else
-        const double beta = q_rcp(nu * xi);                       // tau / xi^2
-#endif
+        q_sqrt_rsqrt(nz ? maxval : 1.0, rootn, rrootn);
+        const double nu = nz ? copysign(rootn, xi1) : -xi1;
+        const double xi = nz ? xi1 + nu : 1.0;
+        const double tj = nz ? __builtin_fma(fabs(xi1), rrootn, 1.0) : 0.0;  // xi / nu
+        const double beta = nz ? q_rcp(nu * xi) : 0.0;                       // tau / xi^2
         if (C.lane == 8 * (j & 7)) {
             *ug = xi;
             *reinterpret_cast<double2 *>(L.scal + ODD * 2) = make_double2(beta, xi);
             *reinterpret_cast<double2 *>(L.rcps + 32 + 2 * j) = make_double2(tj, nu);
         }
     }
-#ifdef QRB_T_NOBAR
-    if (C.real) QB_BARRIER();
-#else
     QB_BARRIER();
-#endif
     {
         const double beta = L.scal[ODD * 2];
         const double2 *uq = reinterpret_cast<const double2 *>(L.ub + (ODD * 8 + C.rg) * UST);
@@ -523,9 +512,6 @@ __device__ __forceinline__ void qrb_step(double (&x)[32], double (&r)[4], const 
         r[2 * JB + ODD] = mine ? x[KK] : r[2 * JB + ODD];
         x[KK] = mine ? 0.0 : x[KK];
     }
-#ifdef QRB_T_NOHELP
-    if (ROLE != 0 && !C.real) return;
-#endif
     if (ROLE == 0) {
         // the next column's raw reflector goes to LDS at once (its diagonal entry is patched when xi is known)
         if (!last && (C.lane >> 3) == ((j + 1) & 7)) {

@@ -66,196 +66,6 @@ typedef const DQMC_GLOBAL d2v *gcd2p;
 // [4 r + g][ci] of a 16 x 16 tile; the A operand is A[i = ci][k = g], the B operand B[k = g][j = ci].
 // S[I][J] (J >= I): tile of S, rows 16 I.., columns 16 J..;  ST[I][J]: tile of S', i.e. ST[I][J][rho][kappa] =
 // S[16 J + kappa][16 I + rho].  Only the upper block triangle of both is kept.
-template <int NB, bool FULL>
-__global__ __launch_bounds__(64) void sweep_lu_kernel(int n, const double *__restrict__ Gall, long strideG,
-                                                     int8_t *__restrict__ conf_slice, long conf_stride, int site0,
-                                                     int nsites, double *__restrict__ img_all, SweepConsts sc,
-                                                     WalkerRng *rngs, DevStats *stats, int check_sign)
-{
-    const int w = blockIdx.x, lane = threadIdx.x, g = lane >> 4, ci = lane & 15;
-    int8_t *__restrict__ cw = conf_slice + (long)w * conf_stride;
-    const int myc = (FULL || lane < nsites) ? (int)cw[site0 + (FULL ? lane : min(lane, nsites - 1))] : 1;
-    const unsigned long long cbits = __ballot(myc > 0);
-    const WalkerRng rs = rngs[w];
-    double uvec;  // lane k: the k-th uniform this chunk consumes, whichever site consumes it (DQMC.jl:573)
-    {
-        const unsigned long long d = rs.draw + (unsigned long long)lane;
-        uvec = rs.uniforms ? (d < rs.n_uniforms ? rs.uniforms[d] : 2.0) : philox_uniform(rs.seed, d);
-    }
-
-    d4 S[NB][4][4], ST[NB][4][4];
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        const double *__restrict__ G = Gall + (long)(w * NB + b) * strideG + (long)site0 * n + site0;
-#pragma unroll
-        for (int I = 0; I < 4; ++I)
-#pragma unroll
-            for (int J = I; J < 4; ++J)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int rho = 16 * I + 4 * r + g, kap = 16 * J + ci;  // S[rho][kap]; ST: S[kap][rho]
-                    if (FULL) {
-                        S[b][I][J][r] = G[rho + (long)n * kap];
-                        ST[b][I][J][r] = G[kap + (long)n * rho];
-                    } else {  // clamped addresses, no per-lane branches; entries outside the chunk are zero
-                        const bool ok = rho < nsites && kap < nsites;
-                        const int rc = min(rho, nsites - 1), kc = min(kap, nsites - 1);
-                        const double a = G[rc + (long)n * kc], c = G[kc + (long)n * rc];
-                        S[b][I][J][r] = ok ? a : 0.0;
-                        ST[b][I][J][r] = ok ? c : 0.0;
-                    }
-                }
-    }
-
-    const double g0 = sc.gamma[0], g1 = sc.gamma[1], e0 = sc.ebos[0], e1 = sc.ebos[1];
-    const double du0 = sc.dup[0], du1 = sc.dup[1], dd0 = sc.ddn[0], dd1 = sc.ddn[1];
-    unsigned long long accbits = 0ull, negbits = 0ull;
-    int ndraw = 0, exhausted = 0;
-    double xall[NB], negv = 0.0;
-#pragma unroll
-    for (int b = 0; b < NB; ++b) xall[b] = 0.0;
-
-#pragma unroll
-    for (int I0 = 0; I0 < 4; ++I0) {
-        if (!FULL && 16 * I0 >= nsites) break;
-        d4 PT[NB], Q[NB];  // ((I - X Uu)^-1)' and (I - L X)^-1 of this diagonal block
-#pragma unroll
-        for (int b = 0; b < NB; ++b)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) PT[b][r] = Q[b][r] = (4 * r + g == ci) ? 1.0 : 0.0;
-#pragma unroll
-        for (int r0 = 0; r0 < 4; ++r0) {
-            double xv4[NB];  // lane group k: x of site 16 I0 + 4 r0 + k (0 if rejected)
-#pragma unroll
-            for (int b = 0; b < NB; ++b) xv4[b] = 0.0;
-            unsigned panel_acc = 0;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int c = 4 * r0 + ks, s = 16 * I0 + c;
-                if (!FULL && s >= nsites) continue;
-                const int src = 16 * ks + c;  // the lane that holds S[s][s] in register r0 of the diagonal tile
-                const int spin = (int)((cbits >> s) & 1ull);
-                double det, p, xb[NB];
-                if (NB == 1) {  // HubbardModelAttractive.jl:113-127
-                    const double d0 = readlane_d(S[0][I0][I0][r0], src);
-                    const double gamma = spin ? g1 : g0;
-                    const double r = 1.0 + gamma * (1.0 - d0);
-                    det = r * r;
-                    p = (spin ? e1 : e0) * det;
-                    xb[0] = gamma / r;  // Attractive.jl:149: x = gamma / (1 + gamma * IG[i])
-                } else {        // HubbardModelRepulsive.jl:128-156,174-191
-                    const double d0 = readlane_d(S[0][I0][I0][r0], src);
-                    const double d1 = readlane_d(S[NB - 1][I0][I0][r0], src);
-                    const double D0 = spin ? du1 : du0, D1 = spin ? dd1 : dd0;
-                    const double R0 = 1.0 + D0 * (1.0 - d0), R1 = 1.0 + D1 * (1.0 - d1);
-                    det = R0 * R1;
-                    p = det;
-                    const double inv_div = 1.0 / det;
-                    xb[0] = (R1 * inv_div) * D0;
-                    xb[NB - 1] = (R0 * inv_div) * D1;
-                    if (check_sign && det < 0.0) {
-                        negbits |= 1ull << s;
-                        negv = lane == s ? det : negv;
-                    }
-                }
-                bool acc;
-                if (p > 1.0) acc = true;  // DQMC.jl:573: rand() is consumed only when p <= 1
-                else {
-                    const double u = readlane_d(uvec, ndraw);
-                    ++ndraw;
-                    if (u == 2.0) exhausted = 1;
-                    acc = u < p;
-                }
-                if (__builtin_amdgcn_readfirstlane((int)acc)) {
-                    accbits |= 1ull << s;
-                    panel_acc |= 1u << ks;
-                    const bool lm = g == ks, lm2 = lm && ci > c;
-#pragma unroll
-                    for (int b = 0; b < NB; ++b) {
-                        const double x = xb[b];
-                        xall[b] = lane == s ? x : xall[b];
-                        xv4[b] = lm ? x : xv4[b];
-                        const double mS = lm2 ? S[b][I0][I0][r0] : 0.0;    // G[s, later columns of the block]
-                        const double mT = lm2 ? ST[b][I0][I0][r0] : 0.0;   // G[later rows of the block, s]
-                        const double aS = x * mT, aT = x * mS;
-                        S[b][I0][I0] = MFMA(aS, mS, S[b][I0][I0]);
-                        ST[b][I0][I0] = MFMA(aT, mT, ST[b][I0][I0]);
-#pragma unroll
-                        for (int J = I0 + 1; J < 4; ++J) {
-                            const double bS = lm ? S[b][I0][J][r0] : 0.0, bT = lm ? ST[b][I0][J][r0] : 0.0;
-                            S[b][I0][J] = MFMA(aS, bS, S[b][I0][J]);
-                            ST[b][I0][J] = MFMA(aT, bT, ST[b][I0][J]);
-                        }
-                        PT[b] = MFMA(aT, lm ? PT[b][r0] : 0.0, PT[b]);  // PT[j][:] += x G[s, j] PT[s][:]
-                        Q[b] = MFMA(aS, lm ? Q[b][r0] : 0.0, Q[b]);     // Q[k][:]  += x G[k, s] Q[s][:]
-                    }
-                }
-            }
-            // the four sites of the panel applied to the later block rows with full k = 4 MFMAs
-            if (I0 < 3 && panel_acc != 0) {
-#pragma unroll
-                for (int b = 0; b < NB; ++b)
-#pragma unroll
-                    for (int I = I0 + 1; I < 4; ++I) {
-                        const double aFS = xv4[b] * ST[b][I0][I][r0], aFT = xv4[b] * S[b][I0][I][r0];
-#pragma unroll
-                        for (int J = I; J < 4; ++J) {
-                            S[b][I][J] = MFMA(aFS, S[b][I0][J][r0], S[b][I][J]);
-                            ST[b][I][J] = MFMA(aFT, ST[b][I0][J][r0], ST[b][I][J]);
-                        }
-                    }
-            }
-        }
-        // block row I0 is final: register images for the flush kernel
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const gdp img = (gdp)(img_all + (long)(w * NB + b) * LU_STRIDE);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                // element [4 r + g][ci] goes to A-operand position (i = 4 r + g, k = ci) of the transposed tile
-                const int tpos = (ci >> 2) * 64 + 16 * (ci & 3) + 4 * r + g;
-#pragma unroll
-                for (int J = I0 + 1; J < 4; ++J) {
-                    img[LU_OFF_U + lu_pair(I0, J) * LU_TILE + r * 64 + lane] = S[b][I0][J][r];
-                    img[LU_OFF_L + lu_pair(I0, J) * LU_TILE + tpos] = ST[b][I0][J][r];
-                }
-                img[LU_OFF_PT + I0 * LU_TILE + tpos] = PT[b][r];
-                img[LU_OFF_Q + I0 * LU_TILE + r * 64 + lane] = Q[b][r];
-            }
-        }
-    }
-    if (!FULL) {  // blocks past the end of a short chunk: identity triangles
-        for (int I0 = (nsites + 15) / 16; I0 < 4; ++I0)
-            for (int b = 0; b < NB; ++b) {
-                const gdp img = (gdp)(img_all + (long)(w * NB + b) * LU_STRIDE);
-                for (int r = 0; r < 4; ++r) {
-                    const double idv = (4 * r + g == ci) ? 1.0 : 0.0;
-                    for (int J = I0 + 1; J < 4; ++J) {
-                        img[LU_OFF_U + lu_pair(I0, J) * LU_TILE + r * 64 + lane] = 0.0;
-                        img[LU_OFF_L + lu_pair(I0, J) * LU_TILE + r * 64 + lane] = 0.0;
-                    }
-                    img[LU_OFF_PT + I0 * LU_TILE + r * 64 + lane] = idv;
-                    img[LU_OFF_Q + I0 * LU_TILE + r * 64 + lane] = idv;
-                }
-            }
-    }
-#pragma unroll
-    for (int b = 0; b < NB; ++b) img_all[(long)(w * NB + b) * LU_STRIDE + LU_IMG + lane] = xall[b];
-    if (lane < nsites && ((accbits >> lane) & 1ull)) cw[site0 + lane] = (int8_t)(-myc);
-    if (lane == 0) {
-        rngs[w].draw = rs.draw + (unsigned long long)ndraw;
-        if (exhausted) rngs[w].exhausted = 1;
-        stats[w].prop_local += nsites;
-        stats[w].acc_local += __popcll(accbits);
-    }
-    if (NB == 2 && negbits != 0ull) {  // sign-problem statistics in site order (DQMC.jl:560-566)
-        for (int s = 0; s < nsites; ++s)
-            if ((negbits >> s) & 1ull) {
-                const double v = readlane_d(negv, s);
-                if (lane == 0) magstats_push(stats[w].negative_probability, v);
-            }
-    }
-}
 
 // ---------------------------------------------------------------------------------------------------------
 // The same elimination on the four SIMDs of a CU: wave J owns block column J of S and of S' (tiles (I, J), I <= J).
@@ -938,17 +748,6 @@ hipError_t launch_sweep_lu(int n, int nb, int n_walkers, const double *G, long s
 {
     if (nsites < 1 || nsites > 64 || site0 < 0 || site0 + nsites > n || nb < 1 || nb > 2) return hipErrorInvalidValue;
     const bool full = nsites == 64;
-    const bool one_wave = getenv("DQMC_SWEEP_LU1") != nullptr;  // single-wave elimination (A/B measurements)
-    if (one_wave) {
-        dim3 grid(n_walkers), block(64);
-#define LU_LAUNCH(NBV, FL)                                                                                        \
-    hipExtLaunchKernelGGL((sweep_lu_kernel<NBV, FL>), grid, block, 0, s, start, stop, 0, n, G, strideG, conf_slice, \
-                          conf_stride, site0, nsites, img, sc, rng, stats, check_sign)
-        if (nb == 1) { if (full) LU_LAUNCH(1, true); else LU_LAUNCH(1, false); }
-        else { if (full) LU_LAUNCH(2, true); else LU_LAUNCH(2, false); }
-#undef LU_LAUNCH
-        return hipGetLastError();
-    }
     int dev = 0;
     (void)hipGetDevice(&dev);
     static unsigned attr_mask = 0;  // per device (function attributes are per device)
@@ -1238,214 +1037,6 @@ __global__ __launch_bounds__(256) void sweep_fused_kernel(SweepFusedArgs a)
                                      a.imgp, a.tiles_m, a.tiles_n);
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// One launch per time slice (round 3): the elimination workgroup of a walker runs its chunks back to back, the flush
-// workgroups of its units apply chunk after chunk, and the two kinds hand over through tagged words in global memory:
-//   E(c) needs F(c - 2) complete for its units (its prologue reads the Green's function with chunks <= c - 2 applied:
-//        the buffer F(c - 1) reads), in steady state long done;
-//   F(c) needs the images of E(c) and every flush workgroup of its unit done with F(c - 1).
-// What this removes from every chunk boundary of the launch-per-chunk form: the launch gap and kernel exit, the
-// dependent HBM read of the walker's RNG record, and - the kernel boundary no longer invalidates the caches - the HBM
-// round trip of the prologue's operands (they come from L2).  Data crosses workgroups under agent-scope release /
-// acquire fences around the flag words (HIP memory model), or - placement permitting - under the lighter pair below.
-// Every wait is bounded, so that a grid that is not co-resident (CUs held by another
-// process) is noticed: all workgroups then leave, *errflag bit 3 is raised and the host reports the call as failed.
-// Selected with DQMC_SWEEP_PERSIST=1 (measured slower than the launch-per-chunk form, see engine.cpp: off by default).
-struct SweepSliceArgs {
-    int n, n_walkers, n_units, nc;
-    double *G0, *G1;            // chunk c: flush reads G(c & 1), writes the other; the result of the slice is in G(nc & 1)
-    long strideG;
-    int8_t *conf_slice;
-    long conf_stride;
-    double *img;                // two image sets: img + (c & 1) * istr
-    long istr;
-    SweepConsts sc;
-    WalkerRng *rngs;
-    DevStats *stats;
-    int check_sign;
-    int *errflag;
-    int tiles_m, tiles_n;
-    unsigned *flags;            // [0] arrivals; [16 + 8 w + c] E(c) of walker w done (tag); [16 + 8 W + 8 u + c] flush workgroups of unit u done with chunk c
-    unsigned launch;            // launch counter of this handle (tags grow monotonically: no reset between launches)
-    int grid_wgs;               // workgroups that take part in the arrival handshake
-    int force_agent;            // DQMC_SLICE_AGENT: memory-model fences regardless of placement
-};
-constexpr int SL_SPIN = 1 << 22;
-// Release / acquire around the hand-over words.  The memory-model form (agent scope) writes the XCD's whole L2 back and
-// invalidates it - on a part with eight L2s that is what makes workgroups of different XCDs see each other's data, but
-// here it would throw away exactly what the one-launch form is for (measured: 214 us per slice against 137 for the
-// launch-per-chunk form).  When the elimination workgroup of a walker and the flush workgroups of its unit have
-// verified at run time (HW_REG_XCC_ID, exchanged during the arrival handshake) that they all sit on ONE XCD, they
-// share that XCD's L2: the writer only has to wait until its stores are in L2 (the vector L1 is write-through:
-// s_waitcnt vmcnt(0)), the reader only has to drop its own L1 (buffer_inv sc0).  Same hardware-behaviour dependency
-// as the cooperative QR's L2-resident mailbox; any other placement takes the agent-scope fences.
-__device__ __forceinline__ void sl_release(bool same_xcd)
-{
-    if (same_xcd) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-}
-__device__ __forceinline__ void sl_acquire(bool same_xcd)
-{
-    if (same_xcd) asm volatile("buffer_inv sc0" ::: "memory");
-    else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-}
-// thread 0 waits until *p >= target (agent scope), everybody leaves through a barrier and the acquire;
-// returns false on time-out / abort
-__device__ __forceinline__ bool sl_wait_ge(unsigned *p, unsigned target, int *abort_lds, bool same_xcd)
-{
-    if (threadIdx.x == 0) {
-        int ok = 0;
-        for (int it = 0; it < SL_SPIN; ++it) {
-            if ((int)(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0) { ok = 1; break; }
-            __builtin_amdgcn_s_sleep(1);
-        }
-        if (!ok) *abort_lds = 1;
-    }
-    __syncthreads();
-    sl_acquire(same_xcd);
-    return *abort_lds == 0;
-}
-template <int NB, int NT, int NCP>
-__global__ __launch_bounds__(256) void sweep_slice_kernel(SweepSliceArgs a)
-{
-    __shared__ int s_abort, s_same;
-    const int tid = threadIdx.x;
-    if (tid == 0) { s_abort = 0; s_same = 0; }
-    __syncthreads();
-    const bool elim = (int)blockIdx.x < a.n_walkers;
-    const int fbid = (int)blockIdx.x - a.n_walkers;
-    const int T = a.tiles_m * a.tiles_n;
-    const int unit = elim ? (int)blockIdx.x * NB : ((fbid >> 3) / T) * 8 + (fbid & 7);
-    if (!elim && unit >= a.n_units) return;  // padding workgroups of the XCD-aware map: never part of anything
-    unsigned *Edone = a.flags + 16, *Fdone = Edone + 8 * a.n_walkers, *xcc = Fdone + 8 * (((a.n_units + 7) / 8) * 8);
-    // ---- every workgroup leaves its XCC id behind; a walker's workgroups compare them when they first need to know
-    // (no launch-wide handshake: the dispatcher takes ~15 us to start the last of the 160 workgroups, and the first
-    // elimination must not wait for that)
-    if (tid == 0) {
-        const unsigned my = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 0xfu;  // HW_REG_XCC_ID[3:0]
-        __hip_atomic_store(&xcc[blockIdx.x], a.launch * 16u + my, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    auto placement = [&]() -> bool {  // false: a workgroup of this walker never showed up (bounded wait)
-        if (tid == 0) {
-            const int w = unit / NB, g8 = unit >> 3;
-            bool same = NB == 1 && !a.force_agent, all = true;
-            unsigned ref = 0;
-            for (int i = 0; i <= T && all; ++i) {
-                const int idx = i == 0 ? w : a.n_walkers + (((g8 * T + (i - 1)) << 3) | (unit & 7));
-                unsigned v = 0;
-                int it = 0;
-                for (; it < SL_SPIN; ++it) {
-                    v = __hip_atomic_load(&xcc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((v >> 4) == a.launch) break;
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                if (it == SL_SPIN) all = false;
-                if (i == 0) ref = v;
-                else same = same && v == ref;
-            }
-            s_same = (all && same) ? 1 : 0;
-            if (!all) s_abort = 1;
-        }
-        __syncthreads();
-        return s_abort == 0;
-    };
-    bool same_xcd = false;
-    if (elim) {
-        const int w = blockIdx.x;
-        for (int c = 0; c < a.nc; ++c) {
-            if (c >= 2)
-                for (int b = 0; b < NB; ++b)
-                    if (!sl_wait_ge(&Fdone[8 * (w * NB + b) + (c - 2)], a.launch * (unsigned)T, &s_abort, same_xcd)) {
-                        if (tid == 0) atomicOr(a.errflag, 8);
-                        return;
-                    }
-            const double *Gin = ((c - 1) & 1) ? a.G1 : a.G0;  // c == 0: G0
-            double *img = a.img + (long)(c & 1) * a.istr;
-            const double *imgp = a.img + (long)((c - 1) & 1) * a.istr;
-            if (c == 0)
-                lu4_block<NB, true, false>(w, a.n, a.G0, a.strideG, a.conf_slice, a.conf_stride, 0, 64, img, a.sc, a.rngs,
-                                           a.stats, a.check_sign, a.errflag, 0, nullptr);
-            else
-                lu4_block<NB, true, true>(w, a.n, Gin, a.strideG, a.conf_slice, a.conf_stride, 64 * c, 64, img, a.sc, a.rngs,
-                                          a.stats, a.check_sign, a.errflag, 64 * (c - 1), imgp);
-            if (c == 0) {
-                if (!placement()) {
-                    if (tid == 0) atomicOr(a.errflag, 8);
-                    return;
-                }
-                same_xcd = s_same != 0;
-            }
-            sl_release(same_xcd);
-            __syncthreads();
-            if (tid == 0) __hip_atomic_store(&Edone[8 * w + c], a.launch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            sl_acquire(same_xcd);  // (my own RNG record / counters / images of the next chunk)
-        }
-    } else {
-        const int w = unit / NB;
-        if (!placement()) {
-            if (tid == 0) atomicOr(a.errflag, 8);
-            return;
-        }
-        same_xcd = s_same != 0;
-        for (int c = 0; c < a.nc; ++c) {
-            bool ok = sl_wait_ge(&Edone[8 * w + c], a.launch, &s_abort, same_xcd);
-            if (ok && c >= 1) ok = sl_wait_ge(&Fdone[8 * unit + (c - 1)], a.launch * (unsigned)T, &s_abort, same_xcd);
-            if (!ok) {
-                if (tid == 0) atomicOr(a.errflag, 8);
-                return;
-            }
-            const double *Gin = (c & 1) ? a.G1 : a.G0;
-            double *Gout = (c & 1) ? a.G0 : a.G1;
-            flush_lu_body<true, NT, NCP>(fbid, a.n, a.n_units, Gin, Gout, a.strideG, 64 * c, 64,
-                                         a.img + (long)(c & 1) * a.istr, a.tiles_m, a.tiles_n);
-            sl_release(same_xcd);
-            __syncthreads();
-            if (tid == 0) __hip_atomic_fetch_add(&Fdone[8 * unit + c], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-}
-
-// flags: [16][8 per walker][8 per unit, units rounded up to 8][one per workgroup of the grid]: zero-initialised once
-size_t sweep_slice_flag_words(int n_walkers, int n_units)
-{
-    const size_t u8 = (size_t)((n_units + 7) / 8) * 8;
-    return 16 + 8 * (size_t)n_walkers + 8 * u8 + (size_t)n_walkers + u8 * 64;
-}
-hipError_t launch_sweep_slice(int n, int nb, int n_walkers, double *G0, double *G1, long strideG, int8_t *conf_slice,
-                              long conf_stride, double *img, long istr, SweepConsts sc, WalkerRng *rng, DevStats *stats,
-                              int check_sign, int *errflag, unsigned *flags, unsigned launch, hipStream_t s,
-                              hipEvent_t start, hipEvent_t stop)
-{
-    if (n % 256 != 0 || n / 64 > 8 || nb < 1 || nb > 2) return hipErrorInvalidValue;
-    const int n_units = n_walkers * nb;
-    SweepSliceArgs a;
-    a.n = n; a.n_walkers = n_walkers; a.n_units = n_units; a.nc = n / 64;
-    a.G0 = G0; a.G1 = G1; a.strideG = strideG; a.conf_slice = conf_slice; a.conf_stride = conf_stride;
-    a.img = img; a.istr = istr; a.sc = sc; a.rngs = rng; a.stats = stats; a.check_sign = check_sign; a.errflag = errflag;
-    a.tiles_m = n / 64; a.tiles_n = n / (16 * 8 * 2);  // NT = 8, two column passes per flush workgroup
-    a.flags = flags; a.launch = launch;
-    a.force_agent = getenv("DQMC_SLICE_AGENT") != nullptr;
-    const int groups = (n_units + 7) / 8;
-    const int flush_blocks = groups * 8 * a.tiles_m * a.tiles_n;
-    a.grid_wgs = n_walkers + n_units * a.tiles_m * a.tiles_n;  // (the padding workgroups leave before the handshake)
-    const size_t lds_flush = ((size_t)LU_STRIDE + 16 * 8 * FL_LDR) * sizeof(double);
-    const size_t lds_lu = nb == 1 ? sizeof(Lu4Smem<1>) : sizeof(Lu4Smem<2>);
-    const size_t lds_pro = nb == 1 ? (sizeof(Lu4Smem<1>) + 15) / 16 * 16 + (LU_STRIDE + 1536 + 1024 + 8) * sizeof(double) : lds_lu;
-    const size_t lds_e = lds_pro > lds_lu ? lds_pro : lds_lu;
-    const size_t lds = lds_flush > lds_e ? lds_flush : lds_e;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    static unsigned attr_mask = 0;
-    if (!(attr_mask & (1u << dev))) {
-        (void)hipFuncSetAttribute((const void *)sweep_slice_kernel<1, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        (void)hipFuncSetAttribute((const void *)sweep_slice_kernel<2, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        attr_mask |= 1u << dev;
-    }
-    dim3 grid(n_walkers + flush_blocks), block(256);
-    if (nb == 1) hipExtLaunchKernelGGL((sweep_slice_kernel<1, 8, 2>), grid, block, lds, s, start, stop, 0, a);
-    else hipExtLaunchKernelGGL((sweep_slice_kernel<2, 8, 2>), grid, block, lds, s, start, stop, 0, a);
-    return hipGetLastError();
-}
 
 hipError_t launch_sweep_flush_lu(int n, int n_units, const double *Gin, double *Gout, long strideG, int site0,
                                  int nsites, const double *img, hipStream_t s, hipEvent_t start, hipEvent_t stop)
@@ -1473,7 +1064,7 @@ hipError_t launch_sweep_flush_lu(int n, int n_units, const double *Gin, double *
     // two column passes per workgroup (one pair of triangular solves per 64-row tile instead of two) when the grid is
     // more than one round of workgroups anyway: 512 units (config 4 on one GPU) 293 -> 230 us; a single round
     // (32 units: 256 workgroups) is faster with one pass each (16.7 vs 24 us).  DQMC_FLUSH_NCP2 forces it.
-    const bool ncp2_env = getenv("DQMC_FLUSH_NCP2") != nullptr;  // (read per launch: the tests toggle it)
+    const bool ncp2_env = kernel_switches().flush_ncp2;
     static int n_cus[32] = {0};
     if (dev >= 0 && dev < 32 && n_cus[dev] == 0) {
         hipDeviceProp_t prop;

@@ -235,7 +235,7 @@ hipError_t launch_trsm_rl(int nr, int nc, int c0, int ld, int nblk_all, int n_un
     }
     const int slabs = (nr + 31) / 32;
     const int groups = (n_units + 7) / 8;
-    if (nc == 256 && nr % 32 == 0 && !getenv("DQMC_TRSM_BOUNDS"))
+    if (nc == 256 && nr % 32 == 0 && !kernel_switches().trsm_bounds)
         hipLaunchKernelGGL(trsm_rl_kernel<true>, dim3(groups * 8 * slabs), dim3(256), lds_r, s, nr, nc, c0, ld, nblk_all, A, sA, T,
                            sT, pivot, Out, sO, slabs, winv, n_units);
     else

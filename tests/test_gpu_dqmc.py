@@ -237,28 +237,29 @@ def test_cooperative_qr_timeout_falls_back(gpu, O):
     assert "fallbacks" in p.stdout
 
 
-@pytest.mark.parametrize("plain", [{"DQMC_NO_SLAB": "1"}, {"DQMC_SWEEP_SPLIT": "1"}, {"DQMC_QR_TAIL": "0"},
+@pytest.mark.parametrize("plain", [{"DQMC_NO_SLAB": "1"}, {"DQMC_SWEEP_SPLIT": "1"},
                                    {"DQMC_SWEEP_SPLIT": "1", "DQMC_FLUSH_NCP2": "1"}, {"DQMC_QR_SC1": "1"},
-                                   {"DQMC_QR_NOCOOP": "1"}, {"DQMC_QR_NOCOOP": "1", "DQMC_QR_TAIL": "0"},
+                                   {"DQMC_QR_NOBLOCKED": "1"}, {"DQMC_QR_NOBLOCKED": "1", "DQMC_QR_SC1": "1"},
+                                   {"DQMC_QR_NOBLOCKED": "1", "DQMC_QR_TAIL": "0"},
+                                   {"DQMC_QR_NOBLOCKED": "1", "DQMC_QR_NOCOOP": "1"},
+                                   {"DQMC_QR_NOBLOCKED": "1", "DQMC_QR_NOCOOP": "1", "DQMC_QR_TAIL": "0"},
+                                   {"DQMC_QRB_SITES": "1"},
                                    {"DQMC_TRSM_LL": "1"}, {"DQMC_TRSM_SIMPLE": "1"}, {"DQMC_SWEEP_OLD": "1"},
-                                   {"DQMC_SWEEP_LU1": "1", "DQMC_SWEEP_SPLIT": "1"}, {"DQMC_SWEEP_PERSIST": "1"},
-                                   {"DQMC_SWEEP_PERSIST": "1", "DQMC_SLICE_AGENT": "1"},
-                                   {"DQMC_OVERLAP": "1"},
-                                   {"DQMC_OVERLAP": "1", "DQMC_OVERLAP_RDIVP": "1", "DQMC_CHAIN_AHEAD": "1"},
-                                   {"DQMC_QR_ROWS": "1"}, {"DQMC_TRSM_BOUNDS": "1"},
-                                   {"DQMC_QR_NOCOOP": "1", "DQMC_QR_TILE_BOUNDS": "1"}],
-                         ids=["slab_chains", "fused_sweep", "two_phase_qr", "two_pass_flush", "qr_sc1_mailbox",
-                              "qr_tile_plus_tail", "qr_tile_only", "trsm_left_looking", "trsm_substitution",
-                              "sweep_round1", "sweep_one_wave", "sweep_one_launch_per_slice", "sweep_one_launch_agent_fences",
-                              "aux_stream_overlap",
-                              "aux_stream_all", "qr_row_split", "trsm_with_bounds", "qr_tile_with_bounds"])
+                                   {"DQMC_TRSM_BOUNDS": "1"},
+                                   {"DQMC_QR_NOBLOCKED": "1", "DQMC_QR_NOCOOP": "1", "DQMC_QR_TILE_BOUNDS": "1"}],
+                         ids=["slab_chains", "fused_sweep", "two_pass_flush", "blocked_udt_sc1_mailbox",
+                              "udt_pivoted_cooperative", "udt_pivoted_cooperative_sc1", "udt_pivoted_cooperative_only",
+                              "udt_pivoted_tile_plus_tail", "udt_pivoted_tile_only", "blocked_udt_slice_sequences_only",
+                              "trsm_left_looking", "trsm_substitution",
+                              "sweep_round1", "trsm_with_bounds", "udt_pivoted_tile_with_bounds"])
 def test_fast_paths_against_their_plain_forms(gpu, plain):
     """The default launch forms at n = 256 (slab-resident product chains, elimination fused with the previous chunk's
-    flush, two-phase QR; the two-pass flush of the throughput regime against the one-pass one) against the forms they
-    replace, selected per handle / per launch through the environment: same seeds, HS field identical, G within the
-    parity tolerance (the forms differ by reassociation only).  qr_sc1_mailbox is the cooperative QR with agent-scope
-    (write-through) packet stores, i.e. the form that stays inside the HIP memory model; the remaining entries are the
-    fallbacks that ship behind switches (single-workgroup QR kernels, round-1 TRSM and sweep kernels)."""
+    flush, the one-launch pre-pivoted UDT; the two-pass flush of the throughput regime against the one-pass one) against
+    the forms they replace, selected per handle through the environment: same seeds, HS field identical, G within the
+    parity tolerance.  The udt_pivoted_* entries run the reference's own pivot rule (UDT.jl:212-246: the cooperative
+    two-phase QR, the tile kernels) in place of the pre-pivoted blocked factorisation - a different column order, the same
+    G; *_sc1_* are the forms whose hand-off stores are agent-scope (write-through), i.e. inside the HIP memory model;
+    the remaining entries are the fallbacks that ship behind switches (round-1 TRSM and sweep kernels)."""
     def run(env):
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)

@@ -110,20 +110,25 @@ def test_udt_panel_kernel_n_above_256(gpu, O, n, batch):
 
 
 def test_two_phase_qr_against_cooperative_alone(gpu):
-    """n = 256: 128 cooperative steps + qr_tail_kernel (one CU per matrix, last 64 steps one column per lane)
-    against the cooperative kernel factoring everything (DQMC_QR_TAIL=0): same pivots, same factors up to rounding"""
+    """n = 256, the pivoted factorisation behind DQMC_QR_NOBLOCKED (more than 32 units per GPU, fallback): 128 cooperative
+    steps + qr_tail_kernel (one CU per matrix, last 64 steps one column per lane) against the cooperative kernel factoring
+    everything (DQMC_QR_TAIL=0): same pivots, same factors up to rounding"""
     import os
     rng = np.random.default_rng(5)
     X = rng.standard_normal((8, 256, 256))
     X[1] *= np.exp(rng.uniform(-20, 20, size=256))[None, :]
     X[2][:, 7] = 0.0                      # a zero column (tau = 0 branch)
     X[3][:, 9] = X[3][:, 200]             # equal norms: the tie goes to the smaller position
-    U1, D1, T1, p1 = gpu.udt_AVX_pivot(X, False)
-    os.environ["DQMC_QR_TAIL"] = "0"
+    os.environ["DQMC_QR_NOBLOCKED"] = "1"   # (the reference's pivot rule; the default at n = 256 is the pre-pivoted one-launch UDT)
     try:
-        U0, D0, T0, p0 = gpu.udt_AVX_pivot(X, False)
+        U1, D1, T1, p1 = gpu.udt_AVX_pivot(X, False)
+        os.environ["DQMC_QR_TAIL"] = "0"
+        try:
+            U0, D0, T0, p0 = gpu.udt_AVX_pivot(X, False)
+        finally:
+            del os.environ["DQMC_QR_TAIL"]
     finally:
-        del os.environ["DQMC_QR_TAIL"]
+        del os.environ["DQMC_QR_NOBLOCKED"]
     for i in range(X.shape[0]):
         assert sorted(p1[i]) == list(range(1, 257))
         if i == 2:  # singular input: D[255] = 0 and T = D^-1 R is not finite (as in the reference); the zero column
@@ -135,46 +140,6 @@ def test_two_phase_qr_against_cooperative_alone(gpu):
         assert (np.abs(rec - X[i]) / scale[None, :]).max() < 1e-12
         assert np.array_equal(p0[i], p1[i])
         assert relerr(D1[i], D0[i]) < 1e-12
-
-
-def test_row_split_qr_against_cooperative(gpu):
-    """n = 256, DQMC_QR_ROWS=1: the first 128 steps by qr_rows_kernel (four workgroups per matrix, rows split, norms
-    down-dated with from-scratch rounds when they cancel) against the default cooperative kernel: same pivots, same
-    factors up to rounding.  Matrices 4..6 are graded the way the matrices of calculate_greens are (a well-conditioned
-    factor between scale matrices spanning tens of decades, by column, by row and both): row grading is where down-dated
-    norms cancel and the from-scratch rounds run."""
-    import os
-    rng = np.random.default_rng(15)
-    X = rng.standard_normal((8, 256, 256))
-    X[1] *= np.exp(rng.uniform(-20, 20, size=256))[None, :]
-    X[2][:, 7] = 0.0
-    X[3][:, 9] = X[3][:, 200]
-    M = rng.standard_normal((3, 256, 256)) / 16 + np.eye(256)
-    X[4] = M[0] * np.exp(-np.log(10.0) * 80 * np.sort(rng.uniform(0, 1, size=256)))[None, :]    # columns: 80 decades
-    # rows over 5 decades, columns over 22 (more row grading and D itself is no longer determined by the data: the
-    # oracle's D moves by O(1) under a 1e-16 perturbation at +-25 on both sides)
-    X[5] = (np.exp(rng.uniform(-6, 6, size=256))[:, None] * M[1]) * np.exp(rng.uniform(-25, 25, size=256))[None, :]
-    X[6] = np.exp(np.linspace(0, -60, 256))[:, None] * M[2]                                      # rows: 26 decades
-    U0, D0, T0, p0 = gpu.udt_AVX_pivot(X, False)
-    os.environ["DQMC_QR_ROWS"] = "1"
-    try:
-        U1, D1, T1, p1 = gpu.udt_AVX_pivot(X, False)
-    finally:
-        del os.environ["DQMC_QR_ROWS"]
-    for i in range(X.shape[0]):
-        assert sorted(p1[i]) == list(range(1, 257))
-        if i == 2:
-            assert p1[i][255] == 8 and D1[i][255] == 0.0
-            continue
-        P = np.zeros((256, 256)); P[np.arange(256), p1[i] - 1] = 1
-        rec = (U1[i] * D1[i]) @ np.triu(T1[i]) @ P
-        scale = np.abs(X[i]).max(axis=0)
-        assert (np.abs(rec - X[i]) / scale[None, :]).max() < 1e-12
-        assert relerr(U1[i].T @ U1[i], np.eye(256)) < 1e-12
-        if np.array_equal(p0[i], p1[i]):
-            assert np.abs(np.log(D1[i] / D0[i])).max() < (1e-9 if i == 5 else 1e-11)
-        else:  # only a near-tie may go the other way (down-dated against from-scratch norms): D agrees to its size
-            assert i >= 4 and np.abs(np.log(D1[i] / D0[i])).max() < 1e-6, i
 
 
 def test_two_phase_qr_many_units(gpu):

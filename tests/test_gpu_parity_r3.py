@@ -169,21 +169,30 @@ def test_magnitude_stats_events(gpu, O, kind, L, beta):
     mc.close()
 
 
-@pytest.mark.parametrize("n,step", [(256, 5), (256, 100), (64, 17)])
-def test_cooperative_qr_dropout_is_recovered(gpu, O, n, step):
+@pytest.mark.parametrize("n,step,env", [(256, 5, {"DQMC_QR_NOBLOCKED": "1"}), (256, 100, {"DQMC_QR_NOBLOCKED": "1"}), (64, 17, {})])
+def test_cooperative_qr_dropout_is_recovered(gpu, O, n, step, env):
     """DQMC_QR_FORCE_TIMEOUT=step:<j>: one of the eight workgroups of every matrix stops publishing at step j.  The
     others run into the bounded spins (a genuine abort: partially written output, tau, pivots), raise the fallback
     word, the tail kernel stands down and the guarded single-workgroup kernel redoes the factorisation from the
-    untouched input.  One launch (the spins take ~0.2 s each)."""
+    untouched input.  One launch (the spins take ~0.2 s each).  (n = 256: the pivoted cooperative QR behind
+    DQMC_QR_NOBLOCKED; the default one-launch UDT reports the time-out instead: next test.)"""
     rng = np.random.default_rng(n + step)
     X = rng.standard_normal((2, n, n))
     X[1] *= np.exp(rng.uniform(-10, 10, size=n))[None, :]
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
     os.environ["DQMC_QR_FORCE_TIMEOUT"] = "step:%d" % step
     try:
         U, D, T, piv = gpu.udt_AVX_pivot(X, False)
-    finally:
         del os.environ["DQMC_QR_FORCE_TIMEOUT"]
-    U0, D0, T0, piv0 = gpu.udt_AVX_pivot(X, False)
+        U0, D0, T0, piv0 = gpu.udt_AVX_pivot(X, False)
+    finally:
+        os.environ.pop("DQMC_QR_FORCE_TIMEOUT", None)
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     for i in range(2):
         P = np.zeros((n, n)); P[np.arange(n), piv[i] - 1] = 1
         rec = (U[i] * D[i]) @ np.triu(T[i]) @ P
@@ -191,6 +200,27 @@ def test_cooperative_qr_dropout_is_recovered(gpu, O, n, step):
         assert (np.abs(rec - X[i]) / scale[None, :]).max() < 1e-12
         assert np.array_equal(piv[i], piv0[i])
         assert relerr(D[i], D0[i]) < 1e-12
+
+
+@pytest.mark.parametrize("step", [3, 20])
+def test_blocked_udt_dropout_is_reported(gpu, step):
+    """The one-launch UDT (csrc/qrb.hip) under the same test hook: part 3 of every matrix stops publishing at step j of its
+    panel, the parts behind it run out of their bounded spins, every workgroup still leaves through its normal path (no
+    hang), the device error word is raised and the CALL FAILS with a message that names the cause - its results are not
+    returned as if they were valid.  (A workgroup only ever waits for lower parts of its own matrix, which in-order
+    dispatch has started before it: the wait cannot fail on a healthy device, so there is no silent second path here.)
+    The next call on the same device is unaffected."""
+    rng = np.random.default_rng(step)
+    X = rng.standard_normal((2, 256, 256))
+    os.environ["DQMC_QR_FORCE_TIMEOUT"] = "step:%d" % step
+    try:
+        with pytest.raises(gpu.DQMCError, match="timed out"):
+            gpu.udt_AVX_pivot(X, True)
+    finally:
+        del os.environ["DQMC_QR_FORCE_TIMEOUT"]
+    U, D, T, piv = gpu.udt_AVX_pivot(X, True)
+    for i in range(2):
+        assert relerr((U[i] * D[i]) @ T[i], X[i]) < 1e-12
 
 
 def test_dropout_through_the_engine_counts_fallbacks(gpu, O):

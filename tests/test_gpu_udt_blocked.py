@@ -82,3 +82,25 @@ def test_blocked_udt_contracts(gpu, apply_pivot, batch):
         # the pivot order is the descending order of the input's column norms
         nrm = (X[i] ** 2).sum(axis=0)[piv[i] - 1]
         assert np.all(np.diff(nrm) <= 1e-12 * nrm[:-1])
+
+
+def test_blocked_udt_singular_and_tied_columns(gpu):
+    """a zero column (UDT.jl:136-138: tau = 0, the column stays as it is, D = 0) sorts last and nothing hangs or spreads;
+    two equal columns keep their input order (first maximum first, UDT.jl:151-168)"""
+    n = 256
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((3, n, n))
+    X[0][:, 7] = 0.0
+    X[1][:, 9] = X[1][:, 200]
+    U, D, T, piv = gpu.udt_AVX_pivot(X, False)
+    assert piv[0][255] == 8 and D[0][255] == 0.0
+    assert np.all(np.isfinite(D[0])) and np.all(D[0][:255] > 0) and np.all(np.isfinite(U[0]))
+    assert relerr(U[0].T @ U[0], np.eye(n)) < 1e-12
+    P = np.zeros((n, n)); P[np.arange(n), piv[0] - 1] = 1
+    R = np.triu(T[0])[:255] * D[0][:255, None]          # (row 255 of T is 0 / 0)
+    assert np.abs(U[0][:, :255] @ R @ P - X[0]).max() < 1e-12
+    i9, i200 = list(piv[1]).index(10), list(piv[1]).index(201)
+    assert i200 == i9 + 1
+    P = np.zeros((n, n)); P[np.arange(n), piv[1] - 1] = 1
+    assert relerr((U[1] * D[1]) @ np.triu(T[1]) @ P, X[1]) < 1e-12
+    assert D[1][i200] < 1e-12 * D[1][i9]                 # the second copy has nothing left once the first is eliminated
