@@ -271,6 +271,7 @@ def main():
         mc.timing_enable(False)
     acc_rate = (a1[1] - a0[1]) / max(1, a1[0] - a0[0])
     qr_fallbacks = mc.qr_fallbacks()
+    device_errors = mc.device_errors()  # the device error word as read after the timed regions (0: no bounded wait ran out)
 
     value = total_walkers * steps / dt
     ms_per_step = dt / steps * 1e3
@@ -299,6 +300,16 @@ def main():
         share = min(1.0, tim.get("flush", (0.0, 0))[1] / chunks) if chunks else 1.0
         F["sweep"] = F["flush"] * (1.0 - share)
         F["flush"] = F["flush"] * share
+    # Fields named pmc_* / mfma_busy_frac / traffic are NOT measured by this run: hardware counters need rocprofv3 passes of
+    # their own, so they come from the committed profile files.  Each carries the commit its file was taken at
+    # (roofline.pmc_commit) and `stale: true` when that is not the commit this library was built from.
+    try:
+        lib_commit = mc_amd.lib().dqmc_build_commit().decode()
+    except Exception:
+        lib_commit = "unknown"
+
+    def stale(file_commit):
+        return not (file_commit and lib_commit.rstrip("+") == str(file_commit) and not lib_commit.endswith("+"))
     pmc = {}
     try:  # PMC passes cannot run inside this process: committed rocprofv3 --pmc summary of the same workload
         import glob
@@ -339,12 +350,15 @@ def main():
             hb = (24.0 * n * n + 8.0 * n) * walkers * nb * launches
             ent["algorithmic_GBps"] = hb / (ms * 1e-3) / 1e9
             ent["frac_of_hbm_peak"] = ent["algorithmic_GBps"] / HBM_PEAK_GBS
-            fe, wr = pmc_sum(("qr_coop", "qr_tail"), "FETCH_SIZE"), pmc_sum(("qr_coop", "qr_tail"), "WRITE_SIZE")
+            qk = ("qrb_udt",) if pmc_sum(("qrb_udt",), "FETCH_SIZE") is not None else ("qr_coop", "qr_tail")
+            fe, wr = pmc_sum(qk, "FETCH_SIZE"), pmc_sum(qk, "WRITE_SIZE")
             if fe is not None and wr is not None:  # KB per launch; gfx950 FETCH_SIZE x2 correction as an upper bound
                 ent["pmc_hbm_bytes_per_batch"] = (2.0 * fe + wr) * 1024.0
                 ent["pmc_GBps"] = ent["pmc_hbm_bytes_per_batch"] / (ms * 1e-3 / launches) / 1e9
                 ent["pmc_frac_of_hbm_peak"] = ent["pmc_GBps"] / HBM_PEAK_GBS
                 ent["pmc_source"] = pmc.get("_file")
+                ent["pmc_commit"] = pmc.get("_commit")
+                ent["stale"] = stale(pmc.get("_commit"))
         if fam == "gemm" and pmc:
             busy, cyc = pmc_sum(("slab_chain",), "SQ_VALU_MFMA_BUSY_CYCLES"), pmc_sum(("slab_chain",), "SQ_BUSY_CYCLES")
             if busy and cyc:
@@ -353,15 +367,19 @@ def main():
                 # against the 71 - 77 TF/s of the MFMA-only probe.  (Round-3 profiles before this fix divided by 4: > 1.)
                 ent["mfma_busy_frac"] = busy / (32.0 * cyc)
                 ent["pmc_source"] = pmc.get("_file")
+                ent["pmc_commit"] = pmc.get("_commit")
+                ent["stale"] = stale(pmc.get("_commit"))
         kernels.append(ent)
     # HBM-side traffic of one full GEMM launch: PMC passes cannot run inside this process; the number comes from the
     # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE profile (gfx950 x2 FETCH correction applied there)
-    traffic = None
+    traffic, traffic_commit = None, None
     try:
         import glob
         pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_gemm.json")))
         if pm and args.config == 3 and walkers == 32:
-            traffic = json.load(open(pm[-1]))["traffic_bytes_per_launch"]
+            tj = json.load(open(pm[-1]))
+            traffic = tj["traffic_bytes_per_launch"]
+            traffic_commit = tj.get("commit")
     except Exception:
         traffic = None
     dom = kernels[0] if kernels else None
@@ -375,14 +393,15 @@ def main():
                    "parallelism": "walkers sharded, %d rank(s)" % n_gpus, "acceptance_rate": acc_rate,
                    "reduction": reduction,
                    # a cooperative-QR launch that timed out and was redone by the guarded kernel is a FAULT of the fast
-                   # path, not a slow run: must be 0 (device_errors: the sweep kernels' bounded waits, checked at every
-                   # synchronisation - a non-zero word would have raised before this line)
-                   "qr_fallbacks": qr_fallbacks, "device_errors": 0},
+                   # path, not a slow run: must be 0; device_errors is the device error word read back after the timed
+                   # regions (sweep-elimination and one-launch-UDT bounded waits)
+                   "qr_fallbacks": qr_fallbacks, "device_errors": device_errors, "library_commit": lib_commit},
         "roofline": {"bound": "mfma", "achieved": whole_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": whole_tflops / FP64_PEAK_TFLOPS,
                      "definition": "SURVEY 8(d): algorithmic flops of the reference algorithm per walker-sweep "
                                    "(%.3f GFLOP at the measured acceptance) x walker-sweeps/s per GPU" % (F["total"] / 1e9),
                      "traffic": traffic,
+                     "pmc_commit": traffic_commit, "stale": (stale(traffic_commit) if traffic is not None else None),
                      "traffic_note": "HBM bytes (PMC FETCH_SIZE + WRITE_SIZE, guide corrections) of one launch of the most "
                                      "frequent MFMA kernel, see profiles/*_pmc_gemm.json (kernel, algorithmic bytes)",
                      "kernels": kernels, "kernel_ms_sum": sum_ms, "kernel_pass_ms_per_step": kp_ms,

@@ -290,6 +290,11 @@ int dqmc_set_checkerboard(dqmc_handle *h, int32_t kmax, int32_t n_mats, const do
  * out (CUs held by another stream for longer than the spins allow), the guarded single-workgroup kernel launched
  * behind it redoes the factorisation, so results stay valid.  This counter reports how often that happened. */
 int dqmc_qr_fallbacks(dqmc_handle *h, int64_t *count);
+/* device error word as it stands (0 = no bounded wait inside a kernel has run out); no reference counterpart: the reference
+ * has no concurrent workgroups (diagnostic next to DQMCAnalysis, src/flavors/DQMC/DQMC.jl:35-47) */
+int dqmc_device_errors(dqmc_handle *h, int32_t *word);
+/* commit the library was built from ("<short hash>[+]"); used by bench.py to tell fresh profile files from stale ones */
+const char *dqmc_build_commit(void);
 
 /* ---- instrumentation ------------------------------------------------------ */
 /* Per-kernel-family device time accumulated with HIP events on the handle's

@@ -118,6 +118,8 @@ SIGNATURES = {
     "dqmc_set_checkerboard": (C.c_int, [_H, C.c_int32, C.c_int32, _dp, C.POINTER(C.c_int32), _dp, _dp,
                               C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "dqmc_qr_fallbacks": (C.c_int, [_H, C.POINTER(C.c_int64)]),
+    "dqmc_device_errors": (C.c_int, [_H, C.POINTER(C.c_int32)]),
+    "dqmc_build_commit": (C.c_char_p, []),
     "dqmc_timing_enable": (C.c_int, [_H, C.c_int32]),
     "dqmc_timing_get": (C.c_int, [_H, _dp, _i64p]),
     "dqmc_mfma_f64_peak": (C.c_int, [C.c_int32, C.c_int32, _dp]),

@@ -1,0 +1,7 @@
+// The commit the library was built from: short hash, "+" appended when the sources differed from it; "unknown" outside git.
+// Recompiled by every make (csrc/Makefile), so that bench.py can mark committed profile files as stale (dqmc_build_commit()).
+#include "../../include/dqmc_hip.h"
+#ifndef DQMC_BUILD_COMMIT
+#define DQMC_BUILD_COMMIT "unknown"
+#endif
+extern "C" const char *dqmc_build_commit(void) { return DQMC_BUILD_COMMIT; }

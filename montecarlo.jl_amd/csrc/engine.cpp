@@ -1717,6 +1717,18 @@ int dqmc_set_checkerboard(dqmc_handle *h, int32_t kmax, int32_t n_mats, const do
     return DQMC_OK;
 }
 
+// the device error word as it stands (not cleared): 0 unless a bounded wait inside a kernel ran out since the last call that
+// reported it (bit 1: sweep elimination hand-off, bit 4: one-launch UDT hand-off)
+int dqmc_device_errors(dqmc_handle *h, int32_t *word)
+{
+    ENTER(h);
+    if (!word) return DQMC_ERR_INVALID;
+    *word = 0;
+    if (!h->qr_ws.errflag) return DQMC_OK;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(word, h->qr_ws.errflag, sizeof(int), hipMemcpyDeviceToHost));
+    return DQMC_OK;
+}
 // diagnostics: cooperative-QR launches whose hand-offs timed out and were redone by the single-workgroup kernel
 int dqmc_qr_fallbacks(dqmc_handle *h, int64_t *count)
 {

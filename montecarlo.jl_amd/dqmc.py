@@ -644,6 +644,12 @@ class DQMC:
         self._c(lib().dqmc_qr_fallbacks(self._h, C.byref(n)))
         return n.value
 
+    def device_errors(self):
+        """device error word (0 unless a bounded wait inside a kernel ran out)"""
+        w = C.c_int32(0)
+        self._c(lib().dqmc_device_errors(self._h, C.byref(w)))
+        return int(w.value)
+
     def timing_enable(self, on=True):
         self._c(lib().dqmc_timing_enable(self._h, int(on)))
 

@@ -12,6 +12,8 @@ min_run = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 flags = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-mllvm",
          "-pragma-unroll-threshold=4000000", "-S", "--cuda-device-only"]
 for f in sorted(os.listdir(root)):
+    if f.endswith(".hip") and len(sys.argv) > 2 and f not in sys.argv[2:]:
+        continue
     if not f.endswith(".hip"):
         continue
     out = os.path.join(tempfile.gettempdir(), f + ".s")
