@@ -49,7 +49,8 @@ constexpr long MB_T = MB_V + 8L * 32 * 256;   // [panel 8][column 32][row 32]
 constexpr long MB_D = MB_T + 8L * 32 * 32;    // [256] diag R
 constexpr long MB_N = MB_D + 256;           // [256] squared column norms of the input
 constexpr long MB_X = MB_N + 256;           // [8] XCC id of each part
-constexpr long MB_GRANULES = MB_X + 8;
+constexpr long MB_P = MB_X + 8;             // [256] position of every input column in the sorted order
+constexpr long MB_GRANULES = MB_P + 256;
 
 #define QB_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
@@ -199,63 +200,63 @@ struct QbLds {
 };
 
 // ---- panel p from the mailbox into LDS: one poll on the granule its owner publishes last, then everything in one batch ----
-template <int P>
+// HALF = 0 / 1: only reflectors 16 HALF .. 16 HALF + 15 with the diagonal block of T that belongs to them (the panel's block
+// reflector is the product of its two halves' block reflectors: the next owner applies the first half while the second is
+// still being factored)
+template <int P, int HALF = -1>
 __device__ __forceinline__ void qrb_fetch(const qword *mb, unsigned tag, const QbLds &L, int tid)
 {
-#ifdef QRB_X_NOFETCH
-    QB_BARRIER();
-    return;
-#endif
-#ifdef QRB_X_DELAY
-    for (int q = 0; q < 400; ++q) __builtin_amdgcn_s_sleep(127);
-#endif
+    constexpr int C0 = HALF < 0 ? 0 : 16 * HALF, NC = HALF < 0 ? 32 : 16;  // reflectors C0 .. C0 + NC - 1
     const int r = tid;
-    // uniform column bases + one 32-bit lane offset: the 64 requests of a pass then share ONE address register (their
+    // uniform column bases + one 32-bit lane offset: the requests of a pass then share ONE address register (their
     // column offsets do not fit the instruction's immediate, and 64 address pairs cost 128 registers)
     const qword *vb = mb + 2 * (MB_V + ((long)P * 32) * 256);
     const unsigned ro = 2u * (unsigned)r;
     const qword *tb = mb + 2 * (MB_T + ((long)P * 32) * 32);
-    const qword *tmine = tb + 2L * ((tid >> 3) * 32 + 4 * (tid & 7));
-    const qword *dmine = mb + 2 * (MB_D + 32 * P + (tid & 31));
+    // my share of T: full panel: column tid >> 3, rows 4 (tid & 7) ..+3; half: entry (row C0 + (tid & 15), column C0 + (tid >> 4))
+    constexpr int NT = HALF < 0 ? 4 : 1;
+    const int tcol = HALF < 0 ? (tid >> 3) : C0 + (tid >> 4), trow = HALF < 0 ? 4 * (tid & 7) : C0 + (tid & 15);
+    const qword *tmine = tb + 2L * (tcol * 32 + trow);
+    const qword *dmine = mb + 2 * (MB_D + 32 * P + C0 + (tid & (NC - 1)));
     QRB_STAMP(8 + 4 * P + 0);
-    (void)g_wait(tb + 2L * (31 * 32 + 31), tag, L.s_abort);
+    (void)g_wait(tb + 2L * ((C0 + NC - 1) * 32 + C0 + NC - 1), tag, L.s_abort);
     QRB_STAMP(8 + 4 * P + 1);
     for (unsigned s = 0; s < QB_SPIN; ++s) {
         bool ok = true;
         // (values go to LDS as they come; a pass with a stale granule is simply repeated)
         if (r >= 32 * P) {
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
+            for (int half = 0; half < NC / 16; ++half) {
                 qword a[16], b[16];
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
-                    const qword *cb = vb + 2L * (16 * half + j) * 256;
+                    const qword *cb = vb + 2L * (C0 + 16 * half + j) * 256;
                     a[j] = __hip_atomic_load(cb + ro, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     b[j] = __hip_atomic_load(cb + ro + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
                     ok = ok & ((unsigned)(a[j] >> 32) == tag) & ((unsigned)(b[j] >> 32) == tag);
-                    L.Vs[(16 * half + j) * VLD + r] = __longlong_as_double((long long)((a[j] & 0xffffffffull) | (b[j] << 32)));
+                    L.Vs[(C0 + 16 * half + j) * VLD + r] = __longlong_as_double((long long)((a[j] & 0xffffffffull) | (b[j] << 32)));
                 }
             }
         }
         {
-            qword a[5], b[5];
+            qword a[NT + 1], b[NT + 1];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < NT; ++j) {
                 a[j] = __hip_atomic_load(tmine + 2 * j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 b[j] = __hip_atomic_load(tmine + 2 * j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            a[4] = __hip_atomic_load(dmine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            b[4] = __hip_atomic_load(dmine + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            a[NT] = __hip_atomic_load(dmine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            b[NT] = __hip_atomic_load(dmine + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-            for (int j = 0; j < 5; ++j) ok = ok & ((unsigned)(a[j] >> 32) == tag) & ((unsigned)(b[j] >> 32) == tag);
+            for (int j = 0; j < NT + 1; ++j) ok = ok & ((unsigned)(a[j] >> 32) == tag) & ((unsigned)(b[j] >> 32) == tag);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                L.Ts[(tid >> 3) * TLD + 4 * (tid & 7) + j] = __longlong_as_double((long long)((a[j] & 0xffffffffull) | (b[j] << 32)));
-            if (tid < 32)
-                L.dinv[32 * P + tid] = 1.0 / fabs(__longlong_as_double((long long)((a[4] & 0xffffffffull) | (b[4] << 32))));
+            for (int j = 0; j < NT; ++j)
+                L.Ts[tcol * TLD + trow + j] = __longlong_as_double((long long)((a[j] & 0xffffffffull) | (b[j] << 32)));
+            if (tid < NC)
+                L.dinv[32 * P + C0 + tid] = 1.0 / fabs(__longlong_as_double((long long)((a[NT] & 0xffffffffull) | (b[NT] << 32))));
         }
         if (ok) break;
         if (((s & 63u) == 63u && abort_get(L.s_abort)) || s + 1 == QB_SPIN) {
@@ -269,9 +270,10 @@ __device__ __forceinline__ void qrb_fetch(const qword *mb, unsigned tag, const Q
 }
 
 // ---- [C Z] <- (I - V_p T_p' V_p') [C Z] on the row tiles t >= 2P ---------------------------------------------------
-template <int P, bool DO_C, bool DO_Z>
+template <int P, bool DO_C, bool DO_Z, int HALF = -1>
 __device__ __forceinline__ void qrb_apply(d4 (&c)[8], d4 (&z)[8], const QbLds &L, int wv, int lane)
 {
+    constexpr int A0 = HALF < 0 ? 0 : HALF, A1 = HALF < 0 ? 2 : HALF + 1;  // tiles of 16 reflectors that take part
 #ifdef QRB_X_NOAPPLY
     return;
 #endif
@@ -284,7 +286,7 @@ __device__ __forceinline__ void qrb_apply(d4 (&c)[8], d4 (&z)[8], const QbLds &L
     }
     // W = V' [C Z], my row tiles only
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
+    for (int a = A0; a < A1; ++a) {
         const double *va = L.Vs + (16 * a + nn) * VLD + kq;
 #pragma unroll
         for (int u = P; u < 8; ++u) {
@@ -301,7 +303,7 @@ __device__ __forceinline__ void qrb_apply(d4 (&c)[8], d4 (&z)[8], const QbLds &L
     {
         double *mine = L.Wx + (wv * 16) * 64 + lane;
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = A0; a < A1; ++a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (DO_C) mine[(a * 4 + r) * 64] = wc[a][r];
@@ -310,7 +312,7 @@ __device__ __forceinline__ void qrb_apply(d4 (&c)[8], d4 (&z)[8], const QbLds &L
         QB_BARRIER();
         const double *other = L.Wx + ((wv ^ 2) * 16) * 64 + lane;
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = A0; a < A1; ++a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (DO_C) wc[a][r] += other[(a * 4 + r) * 64];
@@ -320,11 +322,11 @@ __device__ __forceinline__ void qrb_apply(d4 (&c)[8], d4 (&z)[8], const QbLds &L
     // Y = -T' W (T upper triangular: block (a, a') only for a <= a')
     d4 yc[2], yz[2];
 #pragma unroll
-    for (int ap = 0; ap < 2; ++ap) {
+    for (int ap = A0; ap < A1; ++ap) {
         yc[ap] = (d4){0.0, 0.0, 0.0, 0.0};
         yz[ap] = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int a = 0; a <= ap; ++a)
+        for (int a = A0; a <= ap; ++a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const double tv = -L.Ts[(16 * ap + nn) * TLD + 16 * a + 4 * r + kq];
@@ -337,7 +339,7 @@ __device__ __forceinline__ void qrb_apply(d4 (&c)[8], d4 (&z)[8], const QbLds &L
     for (int u = P; u < 8; ++u) {
         const int t = 2 * u + rh;
 #pragma unroll
-        for (int ap = 0; ap < 2; ++ap)
+        for (int ap = A0; ap < A1; ++ap)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const double av = L.Vs[(16 * ap + 4 * r + kq) * VLD + 16 * t + nn];
@@ -686,8 +688,11 @@ __device__ __forceinline__ void qrb_panel(d4 (&c)[8], d4 (&z)[8], const QbLds &L
         qrb_fetch<P>(mb, tag, L, tid);
         qrb_apply<P, false, true>(c, z, L, wv, lane);
     } else if (P == W - 1) {
-        qrb_fetch<P>(mb, tag, L, tid);
-        qrb_apply<P, true, false>(c, z, L, wv, lane);
+        // I am the next owner: the first 16 reflectors are applied while the second 16 are still being factored
+        qrb_fetch<P, 0>(mb, tag, L, tid);
+        qrb_apply<P, true, false, 0>(c, z, L, wv, lane);
+        qrb_fetch<P, 1>(mb, tag, L, tid);
+        qrb_apply<P, true, false, 1>(c, z, L, wv, lane);
 #ifdef QRB_X_DUMP
         if (W == 1) {
             const int nn = lane & 15, kq = lane >> 4, ct = wv & 1, rh = wv >> 1;
@@ -791,16 +796,26 @@ __global__ __launch_bounds__(QB_THREADS) void qrb_udt_kernel(int n_units, const 
     bool local = force_sc1 == 0;
 #pragma unroll
     for (int q = 1; q < 8; ++q) local = local && L.xcc[q] == L.xcc[0];
-    // ---- position of every column: descending norm, first maximum first (UDT.jl:151-168 for the first step) ----
+    // ---- position of every column: descending norm, first maximum first (UDT.jl:151-168 for the first step).  Every part
+    // ranks its own 32 columns (8 lanes per column, 32 comparisons each) and the 256 positions cross in a second exchange:
+    // 0.3 us + one hop instead of 256 comparisons per thread (7 us)
     {
-        const double my = L.nrm[tid];
-        int rank = 0;
-        const double2 *np2 = reinterpret_cast<const double2 *>(L.nrm);
-        for (int k = 0; k < 256; k += 2) {
+        const int cc = tid >> 3, rg = tid & 7, col = 32 * part + cc;
+        const double my = L.nrm[col];
+        const double2 *np2 = reinterpret_cast<const double2 *>(L.nrm + 32 * rg);
+        int cnt = 0;
+#pragma unroll
+        for (int k = 0; k < 32; k += 2) {
             const double2 o = np2[k >> 1];
-            rank += (o.x > my) | ((o.x == my) & (k < tid));
-            rank += (o.y > my) | ((o.y == my) & (k + 1 < tid));
+            const int k0 = 32 * rg + k;
+            cnt += (o.x > my) | ((o.x == my) & (k0 < col));
+            cnt += (o.y > my) | ((o.y == my) & (k0 + 1 < col));
         }
+        cnt += __builtin_amdgcn_mov_dpp(cnt, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+        cnt += __builtin_amdgcn_mov_dpp(cnt, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+        cnt += __builtin_amdgcn_mov_dpp(cnt, 0x141, 0xf, 0xf, true);  // row_half_mirror
+        if (rg == 0) g_put<false>(mb + 2 * (MB_P + col), (double)cnt, tag);
+        const int rank = (int)g_wait(mb + 2 * (MB_P + tid), tag, L.s_abort);
         L.ord[rank & 255] = tid;  // (ranks are a permutation unless a norm is NaN; ord starts as the identity)
     }
     __syncthreads();

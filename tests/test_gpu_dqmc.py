@@ -150,6 +150,47 @@ def test_cfg5_shape_n576(gpu, O):
     mc.close()
 
 
+@pytest.mark.parametrize("env", [{}, {"DQMC_QR_NOPANEL": "1"}], ids=["panel_qr", "streaming_qr"])
+def test_cfg5_full_depth_against_the_oracle(gpu, O, env):
+    """BASELINE config 5 at its FULL depth against the oracle (stack.jl:242-255, 337-393): 24x24, beta = 20, dtau = 0.05
+    (n = 576, 400 slices, a stack of K = 40 decompositions - the deep-stabilisation case the configuration exists for):
+    prepare() (build_stack + the Green's function at slice M from a 40-deep stack) and the first safe_mult + 1 updates
+    (one stabilisation step on the deep stack, on the way down).  This is where the panel QR's down-dated norms
+    (qr_panel_kernel: the one departure from the reference's from-scratch norms, UDT.jl:151-168) would show if they
+    picked worse pivots; the second parametrisation runs the streaming kernel with the reference's arithmetic.
+    The oracle's dense products go through OpenBLAS here (same algorithm, other summation order; ~1-2 min of CPU)."""
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    blas = O.use_openblas_dgemm(True)
+    try:
+        model = gpu.HubbardModelAttractive(24, 2)
+        mc = gpu.DQMC(model, beta=20.0, delta_tau=0.05, n_walkers=1, seed=11)
+        assert mc.p.slices == 400 and mc.p.safe_mult == 10
+        o = O.OracleDQMC(24, "attractive", beta=20.0, delta_tau=0.05)
+        o.set_conf(mc.conf(0)); o.seed(mc.seeds[0])
+        mc.prepare(); o.prepare()
+        e0 = relerr(mc.greens_eff(0)[0], o.greens_eff()[0])
+        assert e0 < TOL, e0
+        for _ in range(11):
+            mc.update(); o.update()
+        assert (mc.current_slice, mc.direction) == (o.current_slice, o.direction)
+        assert np.array_equal(mc.conf(0), o.conf())
+        e1 = relerr(mc.greens_eff(0)[0], o.greens_eff()[0])
+        assert e1 < TOL, e1
+        a, st = mc.analysis(0), o.stats()
+        assert (a.prop_local, a.acc_local) == (st.prop_local, st.acc_local)
+        assert a.propagation_error.count == st.propagation_error.count
+        print("cfg5 depth: G error after prepare %.2e, after 11 updates %.2e (OpenBLAS oracle: %s)" % (e0, e1, blas))
+        mc.close()
+    finally:
+        O.use_openblas_dgemm(False)
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def test_ed_known_answer_on_gpu(gpu):
     """test/ED/ED_tests.jl:91-176 on the product path: mean Green's function of the 2x2 Hubbard
     models (U=1, t=1, beta=1, dtau=0.1, safe_mult=5; mu=1 for the attractive model) from run()
