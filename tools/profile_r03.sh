@@ -19,7 +19,7 @@ rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES
 rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS -d $OUT/pmc_sq2 -- python3 $R/tools/pmc_lds.py > /dev/null 2> $OUT/pmc_sq2.err || echo "pmc sq2 failed"
 rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES -d $OUT/pmc_sq3 -- python3 $R/tools/pmc_gemm.py > /dev/null 2> $OUT/pmc_sq3.err || echo "pmc sq3 failed"
 cd $R
-python3 tools/pmc_parse_r03.py $OUT "$COMMIT" $OUT/summary/r03_pmc_summary.json $OUT/summary/r03_pmc_gemm.json 2> $OUT/parse.err
+python3 tools/pmc_parse.py $OUT "$COMMIT" $OUT/summary/r03_pmc_summary.json $OUT/summary/r03_pmc_gemm.json 2> $OUT/parse.err
 ST=$(find $OUT/trace -name "*kernel_stats.csv" | head -1)
 if [ -n "$ST" ]; then (echo "# rocprofv3 --kernel-trace --stats of: bench.py --steps 5 --warmup 1 --no-cpu-baseline; library built from commit $COMMIT"; cat $ST) > $OUT/summary/r03_kernel_stats.csv; fi
 ls $OUT/summary
