@@ -261,7 +261,10 @@ int dqmc_get_reduced_stats(dqmc_handle *h, dqmc_stats *out);
 int dqmc_vmul(int32_t device_id, int32_t n, int32_t batch, int32_t transa, int32_t transb,
               const double *A, const double *B, double *C);
 /* udt_AVX_pivot!(U, D, T, pivot, temp, Val(apply)) (src/linalg/UDT.jl:192-306);
- * T holds the input on entry and T on exit */
+ * T holds the input on entry and T on exit.  The reference's contracts hold (test/slice_matrices.jl:202-234:
+ * U unitary, U*Diagonal(D)*T = input resp. U*D*UpperTriangular(T)*P = input with P[i, pivot[i]] = 1).  At n = 256 and up to
+ * 32 matrices the pivot order is the descending order of the INPUT's column norms (one-launch blocked factorisation), not the
+ * step-by-step search of UDT.jl:212-246: D is then not sorted; DQMC_QR_NOBLOCKED=1 selects the reference's rule. */
 int dqmc_udt_pivot(int32_t device_id, int32_t n, int32_t batch, double *U, double *D, double *T,
                    int64_t *pivot, int32_t apply_pivot);
 /* rdivp!(A, T, O, pivot) (src/linalg/general.jl:138-166) */

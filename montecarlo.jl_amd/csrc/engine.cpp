@@ -107,6 +107,7 @@ struct dqmc_handle {
     size_t red_cap = 0;
     dqmc_stats red_stats{};
     bool red_valid = false;
+    size_t red_sizes[4] = {0, 0, 0, 0};  // section sizes of the LAST reduction (dqmc_get_reduced checks against these)
 };
 
 // ---------------------------------------------------------------------------
@@ -1385,6 +1386,7 @@ int dqmc_set_pair_directions(dqmc_handle *h, const int32_t *dir_of, int32_t n_di
     CHK(dalloc(h, &h->dir_ptr, (size_t)n_dirs + 1));
     h->n_dirs = n_dirs;
     h->corr_n = 4 * (size_t)n_dirs + 3 * (size_t)n + 1;
+    h->red_valid = false;  // (re)sized: the last reduction is void
     CHK(dalloc(h, &h->corr_per_walker, (size_t)h->W * 4 * n_dirs));
     CHK(dalloc(h, &h->corr_acc, h->corr_n));
     HIPCHK(hipMemcpy(h->dir_ptr, ptr.data(), sizeof(int) * (n_dirs + 1), hipMemcpyHostToDevice));
@@ -1439,6 +1441,7 @@ int dqmc_set_local_targets(dqmc_handle *h, const int32_t *trg_of, int32_t K)
     HIPCHK(hipStreamSynchronize(h->stream));
     h->K_loc = K;
     h->pc_n = (size_t)h->n_dirs * K * K + 1;
+    h->red_valid = false;
     CHK(dalloc(h, &h->trg_of, (size_t)n * K));
     CHK(dalloc(h, &h->pc_per_walker, (size_t)h->W * (h->pc_n - 1)));
     CHK(dalloc(h, &h->pc_acc, h->pc_n));
@@ -1489,6 +1492,7 @@ int dqmc_accumulator_size(dqmc_handle *h, size_t *n)
 int dqmc_reset_accumulators(dqmc_handle *h)
 {
     ENTER(h);
+    h->red_valid = false;  // (the last reduction no longer describes the accumulators)
     HIPCHK(hipMemsetAsync(h->acc, 0, h->acc_n * sizeof(double), h->stream));
     if (h->corr_acc) HIPCHK(hipMemsetAsync(h->corr_acc, 0, h->corr_n * sizeof(double), h->stream));
     if (h->pc_acc) HIPCHK(hipMemsetAsync(h->pc_acc, 0, h->pc_n * sizeof(double), h->stream));
@@ -1542,6 +1546,7 @@ static int red_pack(dqmc_handle *h)
     CHK(put(h->corr_acc, h->corr_n));
     CHK(put(h->pc_acc, h->pc_n));
     if (h->ut) CHK(put(h->ut->sus_acc, h->ut->sus_n));
+    h->red_sizes[0] = h->acc_n; h->red_sizes[1] = h->corr_n; h->red_sizes[2] = h->pc_n; h->red_sizes[3] = h->ut ? h->ut->sus_n : 0;
     // counters of the local walkers, reduced on the host in walker order
     std::vector<DevStats> st(h->W);
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -1665,8 +1670,10 @@ int dqmc_get_reduced(dqmc_handle *h, int32_t which, double *host_out)
     size_t off = 0;
     for (int i = 0; i < which; ++i) off += sizes[i];
     if (sizes[which] == 0) return fail(h, DQMC_ERR_STATE, "dqmc_get_reduced: this accumulator is not configured");
-    if (red_nsum(h) != sizes[0] + sizes[1] + sizes[2] + sizes[3] + RED_STAT_SUMS || h->red_cap < red_nsum(h) + 4)
-        return fail(h, DQMC_ERR_STATE, "accumulators were reconfigured after the last reduction");
+    for (int i = 0; i < 4; ++i)  // (sizes as they are NOW against the sizes that were packed)
+        if (sizes[i] != h->red_sizes[i])
+            return fail(h, DQMC_ERR_STATE, "accumulators were reconfigured after the last reduction: call dqmc_reduce again");
+    if (h->red_cap < red_nsum(h) + 4) return fail(h, DQMC_ERR_STATE, "call dqmc_reduce first");
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(host_out, h->red_buf + off, sizes[which] * sizeof(double), hipMemcpyDeviceToHost));
     return DQMC_OK;

@@ -575,6 +575,7 @@ static int ut_sus_layout(dqmc_handle *h)
     const size_t want = 4 * (size_t)h->n_dirs + (size_t)h->n_dirs * h->K_loc * h->K_loc + 1;
     if (u->sus_n == want) return 0;
     u->sus_n = want;
+    h->red_valid = false;  // (re)sized: the last reduction is void
     CHK(dalloc(h, &u->sus_per_walker, (size_t)h->W * (want - 1)));
     CHK(dalloc(h, &u->sus_acc, want));
     return 0;
