@@ -280,12 +280,13 @@ def main():
     bounds = {"gemm": "mfma", "flush": "mfma", "qr": "latency", "trsm": "latency", "sweep": "latency", "misc": "hbm"}
     notes = {
         "gemm": "slab_chain_kernel (the safe_mult slice products of a stack interval in one launch, wrap_greens in one "
-                "launch) + gemm_kernel<TA,TB> (the GEMMs of calculate_greens and of compact-WY Q)",
+                "launch) + gemm_kernel<TA,TB> (the GEMMs of calculate_greens; of compact-WY Q only without the one-launch UDT)",
         "flush": "sweep_flush_lu_kernel, last chunk of a slice only (the other chunks are applied inside the fused "
                  "sweep launches): block-triangular solves + a K=64 update of G (MFMA); HBM side 16 n^2 B per unit "
                  "and launch",
-        "qr": "pivoted Householder QR (n sequential column steps per factorisation): qr_coop_kernel (steps 0..127, "
-              "8 workgroups per matrix) + qr_tail_kernel (steps 128..255 on one CU per matrix)",
+        "qr": "udt_AVX_pivot! - n = 256, <= 32 units: qrb_udt_kernel, ONE launch per UDT (pre-pivoted blocked Householder QR, 8 "
+              "workgroups per matrix own a panel each, block reflectors on MFMA, Q, D and T included; its flops here = "
+              "factorisation + norms + explicit Q); otherwise qr_coop_kernel + qr_tail_kernel (pivoted, Q as GEMMs)",
         "trsm": "rdivp! and the compact-WY triangle (blocked substitution, MFMA)",
         "sweep": "sweep_lu4_kernel / sweep_fused_kernel: Metropolis decisions = conditional elimination of G[c,c] "
                  "(sequential site chain), fused with the flush of the previous chunk when the grid is co-resident; "
@@ -295,6 +296,14 @@ def main():
     # rank-1 flops by where they are applied: of the 2M * ceil(N/64) chunk flushes per sweep the `flush` family runs
     # only the stand-alone launches (the last chunk of every slice when the fused form is active); the others happen
     # inside sweep_fused_kernel and are credited to `sweep`
+    # the one-launch UDT forms Q inside the factorisation kernel: the 4/3 n^3 of "Calculate Q" (UDT.jl:250-266) per UDT then
+    # belong to the qr family (2K slice-sequence UDTs at call site 0, 2K + 2K inside calculate_greens at sites 1 and 2)
+    udt_sites = mc.udt_one_launch_sites()
+    qshare = sum(1 for b_ in range(3) if (udt_sites >> b_) & 1) / 3.0
+    if qshare > 0:
+        qflops = float(nb) * n ** 3 * 8 * K * qshare
+        F["gemm"] -= qflops
+        F["qr"] += qflops
     if tim:
         chunks = 2.0 * M * ((n + 63) // 64) * steps
         share = min(1.0, tim.get("flush", (0.0, 0))[1] / chunks) if chunks else 1.0
@@ -395,7 +404,8 @@ def main():
                    # a cooperative-QR launch that timed out and was redone by the guarded kernel is a FAULT of the fast
                    # path, not a slow run: must be 0; device_errors is the device error word read back after the timed
                    # regions (sweep-elimination and one-launch-UDT bounded waits)
-                   "qr_fallbacks": qr_fallbacks, "device_errors": device_errors, "library_commit": lib_commit},
+                   "qr_fallbacks": qr_fallbacks, "device_errors": device_errors, "library_commit": lib_commit,
+                   "udt_one_launch_sites": udt_sites},
         "roofline": {"bound": "mfma", "achieved": whole_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": whole_tflops / FP64_PEAK_TFLOPS,
                      "definition": "SURVEY 8(d): algorithmic flops of the reference algorithm per walker-sweep "

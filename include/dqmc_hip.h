@@ -293,6 +293,10 @@ int dqmc_set_checkerboard(dqmc_handle *h, int32_t kmax, int32_t n_mats, const do
  * out (CUs held by another stream for longer than the spins allow), the guarded single-workgroup kernel launched
  * behind it redoes the factorisation, so results stay valid.  This counter reports how often that happened. */
 int dqmc_qr_fallbacks(dqmc_handle *h, int64_t *count);
+/* which call sites of udt_AVX_pivot! (UDT.jl:192-306) this handle serves with the one-launch pre-pivoted factorisation:
+ * bit 0 add_slice_sequence_left/right (stack.jl:272-311) and other callers, bit 1 / bit 2 the two factorisations of
+ * calculate_greens_AVX! (stack.jl:349, :376); 0 = the reference's pivot rule everywhere (n != 256, > 32 units, DQMC_QR_NOBLOCKED) */
+int dqmc_udt_one_launch_sites(dqmc_handle *h, int32_t *mask);
 /* device error word as it stands (0 = no bounded wait inside a kernel has run out); no reference counterpart: the reference
  * has no concurrent workgroups (diagnostic next to DQMCAnalysis, src/flavors/DQMC/DQMC.jl:35-47) */
 int dqmc_device_errors(dqmc_handle *h, int32_t *word);

@@ -119,6 +119,7 @@ SIGNATURES = {
                               C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "dqmc_qr_fallbacks": (C.c_int, [_H, C.POINTER(C.c_int64)]),
     "dqmc_device_errors": (C.c_int, [_H, C.POINTER(C.c_int32)]),
+    "dqmc_udt_one_launch_sites": (C.c_int, [_H, C.POINTER(C.c_int32)]),
     "dqmc_build_commit": (C.c_char_p, []),
     "dqmc_timing_enable": (C.c_int, [_H, C.c_int32]),
     "dqmc_timing_get": (C.c_int, [_H, _dp, _i64p]),

@@ -1736,6 +1736,15 @@ int dqmc_device_errors(dqmc_handle *h, int32_t *word)
     HIPCHK(hipMemcpy(word, h->qr_ws.errflag, sizeof(int), hipMemcpyDeviceToHost));
     return DQMC_OK;
 }
+// which call sites of udt_AVX_pivot! take the one-launch pre-pivoted form (bit 0: slice-sequence builds and every other caller,
+// bit 1 / 2: first / second factorisation of calculate_greens_AVX!); 0 = the pivoted multi-launch form everywhere
+int dqmc_udt_one_launch_sites(dqmc_handle *h, int32_t *mask)
+{
+    if (!h || !mask) return DQMC_ERR_INVALID;
+    *mask = h->qrb_sites;
+    return DQMC_OK;
+}
+
 // diagnostics: cooperative-QR launches whose hand-offs timed out and were redone by the single-workgroup kernel
 int dqmc_qr_fallbacks(dqmc_handle *h, int64_t *count)
 {

@@ -644,6 +644,12 @@ class DQMC:
         self._c(lib().dqmc_qr_fallbacks(self._h, C.byref(n)))
         return n.value
 
+    def udt_one_launch_sites(self):
+        """bit mask of the udt_AVX_pivot! call sites served by the one-launch pre-pivoted factorisation (0: none)"""
+        w = C.c_int32(0)
+        self._c(lib().dqmc_udt_one_launch_sites(self._h, C.byref(w)))
+        return int(w.value)
+
     def device_errors(self):
         """device error word (0 unless a bounded wait inside a kernel ran out)"""
         w = C.c_int32(0)
