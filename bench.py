@@ -302,6 +302,9 @@ def main():
     qshare = sum(1 for b_ in range(3) if (udt_sites >> b_) & 1) / 3.0
     if qshare > 0:
         qflops = float(nb) * n ** 3 * 8 * K * qshare
+        # ... and inside calculate_greens_AVX! the launch also forms the product that follows the decomposition (Ul Q, stack.jl:360;
+        # Tl Q, :378) by carrying Ul' / Tl' instead of the identity through the reflectors: 2K products of 2 n^3 per call site
+        qflops += float(nb) * n ** 3 * 4 * K * (((udt_sites >> 1) & 1) + ((udt_sites >> 2) & 1))
         F["gemm"] -= qflops
         F["qr"] += qflops
     if tim:

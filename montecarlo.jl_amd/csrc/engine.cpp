@@ -392,10 +392,13 @@ static int udt_formq(dqmc_handle *h, double *Uout, QrSet &q, double *winv, doubl
 }
 // n == 256: the whole of udt_AVX_pivot! in one launch, pivot order fixed up front (qrb.hip).  site: see DQMC_QRB_SITES
 static bool udt_is_fused(const dqmc_handle *h, int site) { return (h->qrb_sites >> site) & 1; }
-static int udt_fused(dqmc_handle *h, const double *A, double *Uout, double *Dout, double *Tout, int apply, QrSet &q)
+// B != null: Uout = B Q (Uout must not be B)
+static int udt_fused(dqmc_handle *h, const double *A, double *Uout, double *Dout, double *Tout, int apply, QrSet &q,
+                     const double *B = nullptr)
 {
     Timed t(h, DQMC_K_QR);
-    HIPCHK(launch_udt_blocked(h->units, A, h->nn, Uout, h->nn, Dout, h->n, Tout, h->nn, q.pivot, &h->qr_ws, apply, h->cur));
+    HIPCHK(launch_udt_blocked(h->units, A, h->nn, Uout, h->nn, Dout, h->n, Tout, h->nn, q.pivot, &h->qr_ws, apply, h->cur, B,
+                              h->nn));
     return 0;
 }
 static int udt(dqmc_handle *h, double *A, double *Uout, double *Dout, double *Tout, int apply)
@@ -428,28 +431,34 @@ static int calculate_greens_src(dqmc_handle *h, double *out, Udt L, Udt R)
     g.colscale = vs_arr(R.d, n);
     g.rowscale = vs_arr(L.d, n);
     CHK(run_gemm(h, g));
-    if (udt_is_fused(h, 1)) {                                          // :349 in one launch (T out of place, in qa.W)
-        CHK(udt_fused(h, out, h->Tr, h->Dr, qa.W, 0, qa));
+    if (udt_is_fused(h, 1)) {
+        // :349 and :360 in one launch: T out of place (qa.W), and the kernel carries Ul' through the reflectors instead of the
+        // identity, so that its "U" is Tl = Ul Q already (Q itself is not used again: :362 overwrites Tr)
+        if (L.u == h->Tl) return fail(h, DQMC_ERR_STATE, "calculate_greens: Ul aliases Tl");
+        CHK(udt_fused(h, out, h->Tl, h->Dr, qa.W, 0, qa, L.u));
         CHK(rdivp_set(h, R.u, qa.W, h->Ur, qa, qa.winv, qa.ts));       // :361
     } else {
-    CHK(udt_factor(h, out, h->Dr, nullptr, 0, qa));                    // :349, first half
-    CHK(rdivp_set(h, R.u, out, h->Ur, qa, qa.winv, qa.ts));            // :361 (out of place: Ur = R.u[:, p] / T)
-    CHK(udt_formq(h, h->Tr, qa, qa.winv, qa.ts));                      // :349, second half
+        CHK(udt_factor(h, out, h->Dr, nullptr, 0, qa));                    // :349, first half
+        CHK(rdivp_set(h, R.u, out, h->Ur, qa, qa.winv, qa.ts));            // :361 (out of place: Ur = R.u[:, p] / T)
+        CHK(udt_formq(h, h->Tr, qa, qa.winv, qa.ts));                      // :349, second half
+        CHK(run_gemm(h, gemm_base(h, U_(h, L.u), 0, U_(h, h->Tr), 0, h->Tl)));    // :360
     }
-    CHK(run_gemm(h, gemm_base(h, U_(h, L.u), 0, U_(h, h->Tr), 0, h->Tl)));    // :360
     g = gemm_base(h, U_(h, h->Tl), 1, U_(h, h->Ur), 0, h->Tr);         // :362 + :368
     g.adddiag = vs_arr(h->Dr, n);
     CHK(run_gemm(h, g));
-    if (udt_is_fused(h, 2)) {                                          // :376 in one launch
-        CHK(udt_fused(h, h->Tr, h->Ul, h->Dr, qb.W, 0, qb));
+    const double *tlul = h->Tr;  // where Tl Ul of :378 ends up
+    if (udt_is_fused(h, 2)) {
+        // :376 and :378 in one launch: "U" = Tl Q goes to Ul (free: the reference's Ul = Q is only used in :378)
+        CHK(udt_fused(h, h->Tr, h->Ul, h->Dr, qb.W, 0, qb, h->Tl));
         CHK(rdivp_set(h, h->Ur, qb.W, h->Ur, qb, qb.winv, qb.ts));     // :377
+        tlul = h->Ul;
     } else {
-    CHK(udt_factor(h, h->Tr, h->Dr, nullptr, 0, qb));                  // :376
-    CHK(rdivp_set(h, h->Ur, h->Tr, h->Ur, qb, qb.winv, qb.ts));        // :377
-    CHK(udt_formq(h, h->Ul, qb, qb.winv, qb.ts));
+        CHK(udt_factor(h, h->Tr, h->Dr, nullptr, 0, qb));                  // :376
+        CHK(rdivp_set(h, h->Ur, h->Tr, h->Ur, qb, qb.winv, qb.ts));        // :377
+        CHK(udt_formq(h, h->Ul, qb, qb.winv, qb.ts));
+        CHK(run_gemm(h, gemm_base(h, U_(h, h->Tl), 0, U_(h, h->Ul), 0, h->Tr)));  // :378
     }
-    CHK(run_gemm(h, gemm_base(h, U_(h, h->Tl), 0, U_(h, h->Ul), 0, h->Tr)));  // :378
-    g = gemm_base(h, U_(h, h->Ur), 0, U_(h, h->Tr), 1, out);           // :382-391
+    g = gemm_base(h, U_(h, h->Ur), 0, U_(h, tlul), 1, out);            // :382-391
     g.kscale = vs_inv(h->Dr, n);
     CHK(run_gemm(h, g));
     return 0;

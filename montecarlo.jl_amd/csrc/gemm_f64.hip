@@ -217,6 +217,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, int tiles_m, int 
     const bool plain = g.rowscale.mode == 0 && g.colscale.mode == 0 && g.adddiag.mode == 0 && m0 + BM <= g.M &&
                        n0 + BN <= g.N;
     if (plain) {  // the common case (chain products, UDT GEMMs): no lookups, no bounds tests
+        double cold[2][2][4];
+        if (g.beta) {  // accumulate: C requested first, all sixteen elements in one batch (was: load, wait, add, store per element)
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        cold[ti][tj][r] = C[(long)g.ldc * (n0 + wn + tj * 16 + lq + 4 * r) + m0 + wm + ti * 16 + li];
+        }
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti) {
             const int m = m0 + wm + ti * 16 + li;
@@ -227,11 +237,56 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, int tiles_m, int 
                     const int n = n0 + wn + tj * 16 + lq + 4 * r;
                     double v = acc[ti][tj][r] * g.alpha;
                     if (m == n) v += g.ident;
-                    double *c = C + (long)g.ldc * n + m;
-                    if (g.beta) v += *c;
-                    *c = v;
+                    if (g.beta) v += cold[ti][tj][r];
+                    C[(long)g.ldc * n + m] = v;
                 }
             }
+        }
+        return;
+    }
+    // Scales that are plain arrays (mode 0 / 1: the products of calculate_greens_AVX!, stack.jl:346-348, :362-368): every
+    // lookup is requested up front with a clamped index, one batch, no branch per value - behind the run-time mode dispatch of
+    // vs_get the 8 + 2 + 2 loads of a lane went out one after the other, each waited for (tools/scan_isa.py: runs of 21)
+    if (g.rowscale.mode <= 1 && g.colscale.mode <= 1 && g.adddiag.mode <= 1) {
+        const double *csd = g.colscale.mode ? g.colscale.d + (long)unit * g.colscale.stride : nullptr;
+        const double *rsd = g.rowscale.mode ? g.rowscale.d + (long)unit * g.rowscale.stride : nullptr;
+        const double *add = g.adddiag.mode ? g.adddiag.d + (long)unit * g.adddiag.stride : nullptr;
+        double csv[2][4] = {{1.0, 1.0, 1.0, 1.0}, {1.0, 1.0, 1.0, 1.0}}, rsv[2] = {1.0, 1.0}, adv[2] = {0.0, 0.0}, cold[2][2][4];
+        const int mc0 = min(m0 + wm + li, g.M - 1), mc1 = min(m0 + wm + 16 + li, g.M - 1);
+        if (csd) {  // (one uniform branch around each batch: a select per value made the compiler branch per value)
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) csv[tj][r] = csd[min(n0 + wn + tj * 16 + lq + 4 * r, g.N - 1)];
+        }
+        if (rsd) { rsv[0] = rsd[mc0]; rsv[1] = rsd[mc1]; }
+        if (add) { adv[0] = add[mc0]; adv[1] = add[mc1]; }
+        if (g.beta) {
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int m = min(m0 + wm + ti * 16 + li, g.M - 1), n = min(n0 + wn + tj * 16 + lq + 4 * r, g.N - 1);
+                        cold[ti][tj][r] = C[(long)g.ldc * n + m];
+                    }
+        }
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) {
+            const int m = m0 + wm + ti * 16 + li;
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = n0 + wn + tj * 16 + lq + 4 * r;
+                    double v = acc[ti][tj][r];
+                    if (g.row_first) { v *= rsv[ti]; v *= csv[tj][r]; } else { v *= csv[tj][r]; v *= rsv[ti]; }
+                    v *= g.alpha;
+                    if (m == n) v += g.ident + adv[ti];
+                    if (g.beta) v += cold[ti][tj][r];
+                    if (m < g.M && n < g.N) C[(long)g.ldc * n + m] = v;
+                }
         }
         return;
     }

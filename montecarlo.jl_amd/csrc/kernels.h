@@ -142,8 +142,11 @@ struct QrCoopWorkspace {
 };
 // udt_AVX_pivot! (UDT.jl:192-306) at n == 256 in one launch: U, D, T = D^-1 R (pivot applied or not, out of place), pivot
 // (0-based positions -> original columns).  Pivot order = descending norm of the input columns (qrb.hip).
+// B (optional, n_units x strideB, must not alias U): U receives B Q instead of Q (the product the reference forms right behind
+// the decomposition in calculate_greens_AVX!, stack.jl:360 / :378)
 hipError_t launch_udt_blocked(int n_units, const double *A, long strideA, double *U, long strideU, double *D, long strideD,
-                              double *T, long strideT, int *pivot, QrCoopWorkspace *ws, int apply_pivot, hipStream_t s);
+                              double *T, long strideT, int *pivot, QrCoopWorkspace *ws, int apply_pivot, hipStream_t s,
+                              const double *B = nullptr, long strideB = 0);
 size_t qrb_mailbox_bytes(int n_units);
 int qrb_blocks_per_cu();
 // ws may be null: single-workgroup kernels only

@@ -728,7 +728,8 @@ __global__ __launch_bounds__(QB_THREADS) void qrb_udt_kernel(int n_units, const 
                                                             double *__restrict__ Dall, long strideD,
                                                             double *__restrict__ Tall, long strideT,
                                                             int *__restrict__ pivall, qword *mailbox, unsigned tag,
-                                                            int *errflag, int apply_pivot, int force_sc1, int force_timeout)
+                                                            int *errflag, int apply_pivot, int force_sc1, int force_timeout,
+                                                            const double *__restrict__ Ball, long strideB)
 {
     extern __shared__ __attribute__((aligned(16))) double qb_lds[];
     QbLds L;
@@ -769,6 +770,7 @@ __global__ __launch_bounds__(QB_THREADS) void qrb_udt_kernel(int n_units, const 
     }
     __syncthreads();
 
+    d4 c[8], z[8];
     // ---- column norms of the input: my 32 original columns, then everybody's through the mailbox ----
     {
         const int cc = tid >> 3, rg = tid & 7, col = 32 * part + cc;
@@ -822,8 +824,7 @@ __global__ __launch_bounds__(QB_THREADS) void qrb_udt_kernel(int n_units, const 
     QRB_STAMP(3);
     if (part == 0) pivall[(long)unit * 256 + tid] = L.ord[tid];
 
-    // ---- my 32 columns (positions 32 part ..) in accumulator layout; Z = my columns of the identity ----
-    d4 c[8], z[8];
+    // ---- my 32 columns (positions 32 part ..) in accumulator layout ----
     {
         const int nn = lane & 15, kq = lane >> 4, ct = wv & 1, rh = wv >> 1;
         const int pos = 32 * part + 16 * ct + nn;
@@ -834,8 +835,26 @@ __global__ __launch_bounds__(QB_THREADS) void qrb_udt_kernel(int n_units, const 
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * (2 * u + rh) + 4 * r + kq;
                 c[u][r] = ac[row - kq];
-                z[u][r] = row == pos ? 1.0 : 0.0;
             }
+    }
+    // Z starts as my columns of the identity (U = Q), or of B' when the caller wants B Q (the product the reference forms right
+    // behind the decomposition, stack.jl:360 / :378) - the block reflectors do not care.  Requested in one batch with my columns
+    // of A just above
+    {
+        const int nn = lane & 15, kq = lane >> 4, ct = wv & 1, rh = wv >> 1;
+        const int pos = 32 * part + 16 * ct + nn;
+        if (Ball) {  // (one uniform branch around the 32 requests: a select per element made each a load -> wait of its own)
+            const double *bp = Ball + (long)unit * strideB + pos + 256 * (16 * rh + kq);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) z[u][r] = bp[256 * (32 * u + 4 * r)];
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) z[u][r] = 16 * (2 * u + rh) + 4 * r + kq == pos ? 1.0 : 0.0;
+        }
     }
     double *__restrict__ Tout = Tall + (long)unit * strideT;
     QRB_STAMP(4);
@@ -906,7 +925,8 @@ int qrb_blocks_per_cu()
 }
 
 hipError_t launch_udt_blocked(int n_units, const double *A, long strideA, double *U, long strideU, double *D, long strideD,
-                              double *T, long strideT, int *pivot, QrCoopWorkspace *ws, int apply_pivot, hipStream_t s)
+                              double *T, long strideT, int *pivot, QrCoopWorkspace *ws, int apply_pivot, hipStream_t s,
+                              const double *B, long strideB)
 {
     if (!ws || !ws->mailbox2) return hipErrorInvalidValue;
     const int blocks = ((n_units + 7) / 8) * 64;
@@ -915,7 +935,7 @@ hipError_t launch_udt_blocked(int n_units, const double *A, long strideA, double
     const unsigned tag = (unsigned)(ws->epoch & 0xffffffffull);
     hipLaunchKernelGGL(qrb_udt_kernel, dim3(blocks), dim3(QB_THREADS), qrb_lds_bytes(), s, n_units, A, strideA, U, strideU, D,
                        strideD, T, strideT, pivot, reinterpret_cast<qword *>(ws->mailbox2), tag, ws->errflag, apply_pivot,
-                       ws->force_sc1, ws->force_timeout);
+                       ws->force_sc1, ws->force_timeout, B, strideB);
     return hipGetLastError();
 }
 

@@ -5,8 +5,8 @@
   pairs - a bounded load sunk into a branch of its own, a kernel at its register limit requesting one element at a time - and
   flat_load / flat_store from pointers whose address space the compiler did not know.  The cures are source idioms that a
   later edit can undo without any numerical test noticing; every kernel has a budget = what it is known to contain today
-  (0 for the kernels that were cleaned, the measured value for those that still carry such runs in cold code: the GEMM's scaled
-  epilogues, the checkerboard factor loads).  tools/scan_isa.py prints the same figures from a fresh compile.
+  (0 for the kernels that were cleaned, the measured value for those that still carry such runs in cold code: the GEMM's
+  generic-mode epilogue, the checkerboard factor loads).  tools/scan_isa.py prints the same figures from a fresh compile.
 * MFMA source-C write-after-read (round 4, tools/scan_mfma_war.py): a load that the register allocator placed in the old
   accumulator registers of an out-of-place v_mfma_f64 right behind it.  Produced wrong results in the one-launch UDT; the
   build patches the assembly of the files that show the pattern.  No shipped kernel may contain it."""
@@ -42,10 +42,12 @@ BUDGET = {
     "qr_panel_kernel<9>": (1, 0),
     "qr_tile256_kernel<true>": (2, 0),
     "udt_finish_kernel": (1, 0),
-    # known, in cold code (scaled / accumulating epilogues behind a run-time mode; the k-loop is clean): VERDICT r3 weak 6
-    "gemm_kernel<false, false, true, 0>": (21, 0),
-    "gemm_kernel<false, true, true, 0>": (21, 0),
-    "gemm_kernel<true, false, true, 0>": (21, 0),
+    # GEMM: k-loop clean; the plain and the array-scaled epilogues (everything the default path launches) request their
+    # loads in batches - the longest run there is the 5-6 of the prologue.  What is left (35) is the generic epilogue behind
+    # vs_get's run-time mode dispatch (conf-derived / inverted / clamped scales): only reached by the non-slab fallbacks
+    "gemm_kernel<false, false, true, 0>": (35, 0),
+    "gemm_kernel<false, true, true, 0>": (35, 0),
+    "gemm_kernel<true, false, true, 0>": (35, 0),
     "gemm_kernel<false, false, false, -1>": (35, 0),
     "cb_apply_kernel<32>": (22, 0),
 }
