@@ -74,6 +74,7 @@ __global__ __launch_bounds__(256) void slab_chain_kernel(SlabArgs a)
     };
 #pragma unroll
     for (int i = 0; i < SL_RING - 1; ++i) issue(i);  // first A operands in flight (HBM latency) before X_0 is staged
+    double csl[2] = {1.0, 1.0};  // column scale of the final store (stack.jl:281 / :305, or eV of the wrap)
     // ---- X_0 slab -> LDS, scaled by pre_1.  All sixteen requests of a thread (and the 32 HS-field bytes of its rows, as
     // four 8-byte words) are in flight together: written as load - scale - store per element, each element waited for
     // its own trip to the L2 (the field byte sat behind a branch): sixteen trips before the first product could start.
@@ -90,6 +91,12 @@ __global__ __launch_bounds__(256) void slab_chain_kernel(SlabArgs a)
         unsigned long long cw[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) cw[i] = pw[i];
+        // (the column scale of the final store travels with the slab, raw and without a branch: one wait for everything)
+        const int gc0 = SL_W * slab + ci;
+        const double *cdp = a.col_d ? a.col_d + (long)unit * a.col_stride + gc0 : X0;
+        const int8_t *ccp = a.col_conf ? a.col_conf + conf_off + gc0 : reinterpret_cast<const int8_t *>(X0);
+        const double cd0 = cdp[0], cd1 = cdp[16];
+        const int8_t cc0 = ccp[0], cc1 = ccp[16];
         asm volatile("" ::: "memory");
         const bool sp = a.st[0].pre_sign > 0, bn = blk != 0;
 #pragma unroll
@@ -106,6 +113,13 @@ __global__ __launch_bounds__(256) void slab_chain_kernel(SlabArgs a)
             v.y *= fy;
             *reinterpret_cast<d2x *>(buf0 + col * SL_LD + r0 + 2 * i) = v;
         }
+        if (a.col_d) {
+            csl[0] = cd0;
+            csl[1] = cd1;
+        } else if (a.col_conf) {
+            csl[0] = ((((cc0 > 0) == (a.col_sign > 0)) != bn)) ? a.epl : a.eml;
+            csl[1] = ((((cc1 > 0) == (a.col_sign > 0)) != bn)) ? a.epl : a.eml;
+        }
     }
     __syncthreads();
 
@@ -117,6 +131,23 @@ __global__ __launch_bounds__(256) void slab_chain_kernel(SlabArgs a)
         for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = (d4){0.0, 0.0, 0.0, 0.0};
+        // The scalings of this step's write-back are requested HERE, ahead of the 512 MFMAs, as one 32-bit word per row tile
+        // (rows 64 w + 16 rt + 4 g .. + 3 of the HS field; a slice starts on a multiple of SL_N bytes): asked for at the
+        // write-back they were eight dependent trips to the L2 per step (post, wait, pre, wait per row tile; each wait also
+        // drained the A operands already in flight for the next step) - 6 of the 19.8 us a step took.
+        const bool last = s + 1 == a.nsteps;
+        const int8_t *c_post = a.st[s].post_conf ? a.st[s].post_conf + conf_off : nullptr;
+        const int8_t *c_pre = (!last && a.st[s + 1].pre_conf) ? a.st[s + 1].pre_conf + conf_off : nullptr;
+        const int s_post = a.st[s].post_sign, s_pre = last ? 0 : a.st[s + 1].pre_sign;
+        unsigned wpost[4] = {0u, 0u, 0u, 0u}, wpre[4] = {0u, 0u, 0u, 0u};
+        if (c_post) {
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) wpost[rt] = *reinterpret_cast<const unsigned *>(c_post + 64 * w + 16 * rt + 4 * g);
+        }
+        if (c_pre) {
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) wpre[rt] = *reinterpret_cast<const unsigned *>(c_pre + 64 * w + 16 * rt + 4 * g);
+        }
         const double *bp = src + ci * SL_LD + 2 * g;  // + 16 ct SL_LD + 8 p
         double2 breg[2][2];                            // [parity of p][ct]
         breg[0][0] = *reinterpret_cast<const double2 *>(bp);
@@ -143,21 +174,20 @@ __global__ __launch_bounds__(256) void slab_chain_kernel(SlabArgs a)
             }
         }
         // ---- write-back: rows 64 w + 16 rt + 4 g + r (r = 0..3), column 16 ct + ci; scale post_s (.) pre_{s+1}
-        const bool last = s + 1 == a.nsteps;
-        const int8_t *c_post = a.st[s].post_conf ? a.st[s].post_conf + conf_off : nullptr;
-        const int8_t *c_pre = (!last && a.st[s + 1].pre_conf) ? a.st[s + 1].pre_conf + conf_off : nullptr;
-        const int s_post = a.st[s].post_sign, s_pre = last ? 0 : a.st[s + 1].pre_sign;
+        const bool bn = blk != 0;
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) {
             const int row = 64 * w + 16 * rt + 4 * g;
             double f[4] = {1.0, 1.0, 1.0, 1.0};
             if (c_post) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) f[r] = slab_conf_val(c_post, row + r, s_post, blk, a.epl, a.eml);
+                for (int r = 0; r < 4; ++r)
+                    f[r] = ((((int8_t)(wpost[rt] >> (8 * r)) > 0) == (s_post > 0)) != bn) ? a.epl : a.eml;
             }
             if (c_pre) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) f[r] *= slab_conf_val(c_pre, row + r, s_pre, blk, a.epl, a.eml);
+                for (int r = 0; r < 4; ++r)
+                    f[r] *= ((((int8_t)(wpre[rt] >> (8 * r)) > 0) == (s_pre > 0)) != bn) ? a.epl : a.eml;
             }
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) {
@@ -171,9 +201,7 @@ __global__ __launch_bounds__(256) void slab_chain_kernel(SlabArgs a)
                     *reinterpret_cast<double2 *>(d + 2) = make_double2(v[2], v[3]);
                 } else {
                     const int gc = SL_W * slab + col;  // global column
-                    double cs = 1.0;
-                    if (a.col_d) cs = a.col_d[(long)unit * a.col_stride + gc];
-                    else if (a.col_conf) cs = slab_conf_val(a.col_conf + conf_off, gc, a.col_sign, blk, a.epl, a.eml);
+                    const double cs = csl[ct];
                     double *o = a.out + (long)unit * a.out_su + (long)SL_N * gc + row;
                     *reinterpret_cast<double2 *>(o) = make_double2(v[0] * cs, v[1] * cs);
                     *reinterpret_cast<double2 *>(o + 2) = make_double2(v[2] * cs, v[3] * cs);
