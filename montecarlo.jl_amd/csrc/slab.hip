@@ -40,12 +40,29 @@ __device__ __forceinline__ double slab_conf_val(const int8_t *conf, int i, int s
     return (plus != (blk != 0)) ? epl : eml;
 }
 
+#ifdef SLAB_STAMPS  // diagnostic build only (tools/slab_stamps.py): shader-clock / 100 MHz stamps of one workgroup
+__device__ long long *slab_stamp_ptr = nullptr;
+#ifndef SLAB_STAMP_BID
+#define SLAB_STAMP_BID 0
+#endif
+#define SLAB_STAMP(k)                                                                                   \
+    do {                                                                                                \
+        if (blockIdx.x == SLAB_STAMP_BID && (threadIdx.x & 63) == 0 && slab_stamp_ptr) {                \
+            slab_stamp_ptr[64 * (threadIdx.x >> 6) + 2 * (k)] = (long long)__builtin_amdgcn_s_memtime(); \
+            slab_stamp_ptr[64 * (threadIdx.x >> 6) + 2 * (k) + 1] = (long long)__builtin_amdgcn_s_memrealtime(); \
+        }                                                                                               \
+    } while (0)
+#else
+#define SLAB_STAMP(k) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(256) void slab_chain_kernel(SlabArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double slab_lds[];
     const int bid = blockIdx.x, xcd = bid & 7, seq = bid >> 3;
     const int unit = (seq >> 3) * 8 + xcd, slab = seq & 7;
     if (unit >= a.n_units) return;
+    SLAB_STAMP(0);
     const int wk = unit / a.nb, blk = unit - wk * a.nb;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, ci = lane & 15;
     double *buf0 = slab_lds, *buf1 = slab_lds + SL_W * SL_LD;
@@ -57,23 +74,19 @@ __global__ __launch_bounds__(256) void slab_chain_kernel(SlabArgs a)
         return a.st[s].A + (long)unit * a.st[s].su + (long)blk * a.st[s].sb + arow + (long)SL_N * (2 * g);
     };
     double areg[SL_RING][4][2];  // [ring slot][row tile][k of the pair]
-    const int total = 32 * a.nsteps;
-    const double *ap = a_ptr(0);
-    int q_issue = 0;  // next pair to load (global pair counter over all steps)
-    auto issue = [&](int slot) {
-        if (q_issue < total) {
-            if ((q_issue & 31) == 0) ap = a_ptr(q_issue >> 5);
-            const double *p = ap + (long)SL_N * 8 * (q_issue & 31);
+    // request of one pair of k columns (8 loads): no condition around it and no branch in the k-loop, see below
+    auto request = [&](int slot, const double *p) {
 #pragma unroll
-            for (int rt = 0; rt < 4; ++rt) {
-                areg[slot][rt][0] = p[16 * rt];
-                areg[slot][rt][1] = p[16 * rt + SL_N];
-            }
+        for (int rt = 0; rt < 4; ++rt) {
+            areg[slot][rt][0] = p[16 * rt];
+            areg[slot][rt][1] = p[16 * rt + SL_N];
         }
-        ++q_issue;
     };
+    {
+        const double *ap0 = a_ptr(0);
 #pragma unroll
-    for (int i = 0; i < SL_RING - 1; ++i) issue(i);  // first A operands in flight (HBM latency) before X_0 is staged
+        for (int i = 0; i < SL_RING - 1; ++i) request(i, ap0 + (long)SL_N * 8 * i);  // in flight before X_0 is staged
+    }
     double csl[2] = {1.0, 1.0};  // column scale of the final store (stack.jl:281 / :305, or eV of the wrap)
     // ---- X_0 slab -> LDS, scaled by pre_1.  All sixteen requests of a thread (and the 32 HS-field bytes of its rows, as
     // four 8-byte words) are in flight together: written as load - scale - store per element, each element waited for
@@ -122,6 +135,7 @@ __global__ __launch_bounds__(256) void slab_chain_kernel(SlabArgs a)
         }
     }
     __syncthreads();
+    SLAB_STAMP(1);
 
     d4 acc[4][2];
     for (int s = 0; s < a.nsteps; ++s) {
@@ -152,15 +166,21 @@ __global__ __launch_bounds__(256) void slab_chain_kernel(SlabArgs a)
         double2 breg[2][2];                            // [parity of p][ct]
         breg[0][0] = *reinterpret_cast<const double2 *>(bp);
         breg[0][1] = *reinterpret_cast<const double2 *>(bp + 16 * SL_LD);
-        for (int p0 = 0; p0 < 32; p0 += SL_RING) {
+        // The k-loop is ONE basic block per SL_RING pairs, and its schedule is written down: in the shadow of every second
+        // MFMA (64 cycles of the pipe, 4 of issue) goes one of the 8 operand requests of pair p + SL_RING - 1 or one of the
+        // two LDS reads of pair p + 1.  Left to itself the compiler emitted the 16 MFMAs of a pair back to back and the ~25
+        // other instructions behind them: the pipe idled ~330 of every 1 350 cycles (tools/slab_stamps.py: 43 300 cycles
+        // per step against 32 768 of MFMA issue).  Hence no branch inside: the stream runs on into the next step's A (the
+        // last step's own A again at the very end - asked for, never used), the B read of pair 32 wraps to pair 0.
+        const double *apc = a_ptr(s), *apn = a_ptr(min(s + 1, a.nsteps - 1));
+#pragma unroll 1
+        for (int p0 = 0; p0 < 32; p0 += SL_RING) {  // (not unrolled further: the written schedule is per SL_RING pairs)
 #pragma unroll
             for (int i = 0; i < SL_RING; ++i) {
-                const int p = p0 + i;
-                issue((i + SL_RING - 1) % SL_RING);
-                if (p + 1 < 32) {
-                    breg[(i + 1) & 1][0] = *reinterpret_cast<const double2 *>(bp + 8 * (p + 1));
-                    breg[(i + 1) & 1][1] = *reinterpret_cast<const double2 *>(bp + 16 * SL_LD + 8 * (p + 1));
-                }
+                const int p = p0 + i, pr = p + SL_RING - 1;
+                request((i + SL_RING - 1) % SL_RING, (pr < 32 ? apc : apn) + (long)SL_N * 8 * (pr & 31));
+                breg[(i + 1) & 1][0] = *reinterpret_cast<const double2 *>(bp + 8 * ((p + 1) & 31));
+                breg[(i + 1) & 1][1] = *reinterpret_cast<const double2 *>(bp + 16 * SL_LD + 8 * ((p + 1) & 31));
 #pragma unroll
                 for (int rt = 0; rt < 4; ++rt) {
                     acc[rt][0] = SLAB_MFMA(areg[i][rt][0], breg[i & 1][0].x, acc[rt][0]);
@@ -171,8 +191,16 @@ __global__ __launch_bounds__(256) void slab_chain_kernel(SlabArgs a)
                     acc[rt][0] = SLAB_MFMA(areg[i][rt][1], breg[i & 1][0].y, acc[rt][0]);
                     acc[rt][1] = SLAB_MFMA(areg[i][rt][1], breg[i & 1][1].y, acc[rt][1]);
                 }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // one operand request
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+                    if (k == 2 || k == 5) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // one LDS read
+                }
             }
         }
+        SLAB_STAMP(2 + 2 * s);
         // ---- write-back: rows 64 w + 16 rt + 4 g + r (r = 0..3), column 16 ct + ci; scale post_s (.) pre_{s+1}
         const bool bn = blk != 0;
 #pragma unroll
@@ -209,8 +237,15 @@ __global__ __launch_bounds__(256) void slab_chain_kernel(SlabArgs a)
             }
         }
         if (!last) SLAB_BARRIER();
+        SLAB_STAMP(3 + 2 * s);
     }
 }
+#ifdef SLAB_STAMPS
+extern "C" int dqmc_debug_slab_stamps(void *devptr)
+{
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(slab_stamp_ptr), &devptr, sizeof(void *));
+}
+#endif
 
 hipError_t launch_slab_chain(const SlabArgs &a, hipStream_t s, hipEvent_t start, hipEvent_t stop)
 {
