@@ -82,11 +82,6 @@ __global__ __launch_bounds__(256) void slab_chain_kernel(SlabArgs a)
             areg[slot][rt][1] = p[16 * rt + SL_N];
         }
     };
-    {
-        const double *ap0 = a_ptr(0);
-#pragma unroll
-        for (int i = 0; i < SL_RING - 1; ++i) request(i, ap0 + (long)SL_N * 8 * i);  // in flight before X_0 is staged
-    }
     double csl[2] = {1.0, 1.0};  // column scale of the final store (stack.jl:281 / :305, or eV of the wrap)
     // ---- X_0 slab -> LDS, scaled by pre_1.  All sixteen requests of a thread (and the 32 HS-field bytes of its rows, as
     // four 8-byte words) are in flight together: written as load - scale - store per element, each element waited for
@@ -110,7 +105,20 @@ __global__ __launch_bounds__(256) void slab_chain_kernel(SlabArgs a)
         const int8_t *ccp = a.col_conf ? a.col_conf + conf_off + gc0 : reinterpret_cast<const int8_t *>(X0);
         const double cd0 = cdp[0], cd1 = cdp[16];
         const int8_t cc0 = ccp[0], cc1 = ccp[16];
+        {   // first A operands: in flight before X_0 is staged, but asked for BEHIND the slab - the wrap's A_1 = G comes from
+            // HBM, and requests retire in order: ahead of the slab they held up its (cache-resident) data
+            const double *ap0 = a_ptr(0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < SL_RING - 1; ++i) request(i, ap0 + (long)SL_N * 8 * i);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         asm volatile("" ::: "memory");
+        SLAB_STAMP(20);  // all prologue requests issued
+#ifdef SLAB_STAMPS
+        asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        SLAB_STAMP(21);  // slab data arrived (the A operands may still be in flight)
+#endif
         const bool sp = a.st[0].pre_sign > 0, bn = blk != 0;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -126,6 +134,7 @@ __global__ __launch_bounds__(256) void slab_chain_kernel(SlabArgs a)
             v.y *= fy;
             *reinterpret_cast<d2x *>(buf0 + col * SL_LD + r0 + 2 * i) = v;
         }
+        SLAB_STAMP(22);  // slab scaled and written to LDS
         if (a.col_d) {
             csl[0] = cd0;
             csl[1] = cd1;

@@ -22,4 +22,7 @@ for rep in range(3):
         dc, dr = cyc - cyc[0], (rt - rt[0]) * 10
         print("wrap rep %d wave %d: cycles %s | ns %s | clock %.2f GHz | k-loops %s cycles" % (
             rep, w, dc.tolist(), dr.tolist(), dc[5] / max(dr[5], 1), [int(cyc[2] - cyc[1]), int(cyc[4] - cyc[3])]), flush=True)
+        if t[w, 20, 0]:
+            print("    prologue: requests issued %d, slab arrived %d, slab in LDS %d, barrier passed %d (cycles after start)" % (
+                t[w, 20, 0] - cyc[0], t[w, 21, 0] - cyc[0], t[w, 22, 0] - cyc[0], cyc[1] - cyc[0]), flush=True)
 mc.close()
