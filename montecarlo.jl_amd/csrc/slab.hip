@@ -63,7 +63,9 @@ __global__ __launch_bounds__(256) void slab_chain_kernel(SlabArgs a)
     const int unit = (seq >> 3) * 8 + xcd, slab = seq & 7;
     if (unit >= a.n_units) return;
     SLAB_STAMP(0);
-    const int wk = unit / a.nb, blk = unit - wk * a.nb;
+    // (nb is 1 or 2 - BlockDiagonal has two blocks, blockdiagonal.jl:13-36: no integer division in the cold prologue, whose
+    // instructions cost an instruction-cache miss per 64 bytes)
+    const int wk = a.nb == 2 ? unit >> 1 : unit, blk = a.nb == 2 ? unit & 1 : 0;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, ci = lane & 15;
     double *buf0 = slab_lds, *buf1 = slab_lds + SL_W * SL_LD;
     const long conf_off = (long)wk * a.conf_stride;
@@ -258,7 +260,7 @@ extern "C" int dqmc_debug_slab_stamps(void *devptr)
 
 hipError_t launch_slab_chain(const SlabArgs &a, hipStream_t s, hipEvent_t start, hipEvent_t stop)
 {
-    if (a.nsteps < 1 || a.nsteps > SLAB_MAX_STEPS) return hipErrorInvalidValue;
+    if (a.nsteps < 1 || a.nsteps > SLAB_MAX_STEPS || a.nb < 1 || a.nb > 2) return hipErrorInvalidValue;
     const size_t lds = 2 * SL_W * SL_LD * sizeof(double);
     int dev = 0;
     (void)hipGetDevice(&dev);
