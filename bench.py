@@ -317,11 +317,14 @@ def main():
     # (roofline.pmc_commit) and `stale: true` when that is not the commit this library was built from.
     try:
         lib_commit = mc_amd.lib().dqmc_build_commit().decode()
+        lib_hash = mc_amd.lib().dqmc_build_source_hash().decode()
     except Exception:
-        lib_commit = "unknown"
+        lib_commit = lib_hash = "unknown"
 
-    def stale(file_commit):
-        return not (file_commit and lib_commit.rstrip("+") == str(file_commit) and not lib_commit.endswith("+"))
+    def stale(file_hash):
+        """a committed profile is stale when the kernel sources it was taken from (csrc/Makefile: SOURCE_HASH, recorded in the
+        file) are not the ones this library was built from; commits that touch only documents / tests / profiles keep it fresh"""
+        return not (file_hash and lib_hash != "unknown" and str(file_hash) == lib_hash)
     pmc = {}
     try:  # PMC passes cannot run inside this process: committed rocprofv3 --pmc summary of the same workload
         import glob
@@ -370,7 +373,7 @@ def main():
                 ent["pmc_frac_of_hbm_peak"] = ent["pmc_GBps"] / HBM_PEAK_GBS
                 ent["pmc_source"] = pmc.get("_file")
                 ent["pmc_commit"] = pmc.get("_commit")
-                ent["stale"] = stale(pmc.get("_commit"))
+                ent["stale"] = stale(pmc.get("_source_hash"))
         if fam == "gemm" and pmc:
             busy, cyc = pmc_sum(("slab_chain",), "SQ_VALU_MFMA_BUSY_CYCLES"), pmc_sum(("slab_chain",), "SQ_BUSY_CYCLES")
             if busy and cyc:
@@ -380,18 +383,18 @@ def main():
                 ent["mfma_busy_frac"] = busy / (32.0 * cyc)
                 ent["pmc_source"] = pmc.get("_file")
                 ent["pmc_commit"] = pmc.get("_commit")
-                ent["stale"] = stale(pmc.get("_commit"))
+                ent["stale"] = stale(pmc.get("_source_hash"))
         kernels.append(ent)
     # HBM-side traffic of one full GEMM launch: PMC passes cannot run inside this process; the number comes from the
     # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE profile (gfx950 x2 FETCH correction applied there)
-    traffic, traffic_commit = None, None
+    traffic, traffic_commit, traffic_hash = None, None, None
     try:
         import glob
         pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_gemm.json")))
         if pm and args.config == 3 and walkers == 32:
             tj = json.load(open(pm[-1]))
             traffic = tj["traffic_bytes_per_launch"]
-            traffic_commit = tj.get("commit")
+            traffic_commit, traffic_hash = tj.get("commit"), tj.get("source_hash")
     except Exception:
         traffic = None
     dom = kernels[0] if kernels else None
@@ -407,14 +410,14 @@ def main():
                    # a cooperative-QR launch that timed out and was redone by the guarded kernel is a FAULT of the fast
                    # path, not a slow run: must be 0; device_errors is the device error word read back after the timed
                    # regions (sweep-elimination and one-launch-UDT bounded waits)
-                   "qr_fallbacks": qr_fallbacks, "device_errors": device_errors, "library_commit": lib_commit,
+                   "qr_fallbacks": qr_fallbacks, "device_errors": device_errors, "library_commit": lib_commit, "library_source_hash": lib_hash,
                    "udt_one_launch_sites": udt_sites},
         "roofline": {"bound": "mfma", "achieved": whole_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": whole_tflops / FP64_PEAK_TFLOPS,
                      "definition": "SURVEY 8(d): algorithmic flops of the reference algorithm per walker-sweep "
                                    "(%.3f GFLOP at the measured acceptance) x walker-sweeps/s per GPU" % (F["total"] / 1e9),
                      "traffic": traffic,
-                     "pmc_commit": traffic_commit, "stale": (stale(traffic_commit) if traffic is not None else None),
+                     "pmc_commit": traffic_commit, "stale": (stale(traffic_hash) if traffic is not None else None),
                      "traffic_note": "HBM bytes (PMC FETCH_SIZE + WRITE_SIZE, guide corrections) of one launch of the most "
                                      "frequent MFMA kernel, see profiles/*_pmc_gemm.json (kernel, algorithmic bytes)",
                      "kernels": kernels, "kernel_ms_sum": sum_ms, "kernel_pass_ms_per_step": kp_ms,

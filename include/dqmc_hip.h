@@ -302,6 +302,9 @@ int dqmc_udt_one_launch_sites(dqmc_handle *h, int32_t *mask);
 int dqmc_device_errors(dqmc_handle *h, int32_t *word);
 /* commit the library was built from ("<short hash>[+]"); used by bench.py to tell fresh profile files from stale ones */
 const char *dqmc_build_commit(void);
+/* hash of the kernel sources the library was built from (csrc/Makefile: SOURCE_HASH); commits that leave the kernels alone
+ * leave it alone - this is what decides whether a committed profile still describes the library */
+const char *dqmc_build_source_hash(void);
 
 /* ---- instrumentation ------------------------------------------------------ */
 /* Per-kernel-family device time accumulated with HIP events on the handle's

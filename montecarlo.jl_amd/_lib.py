@@ -121,6 +121,7 @@ SIGNATURES = {
     "dqmc_device_errors": (C.c_int, [_H, C.POINTER(C.c_int32)]),
     "dqmc_udt_one_launch_sites": (C.c_int, [_H, C.POINTER(C.c_int32)]),
     "dqmc_build_commit": (C.c_char_p, []),
+    "dqmc_build_source_hash": (C.c_char_p, []),
     "dqmc_timing_enable": (C.c_int, [_H, C.c_int32]),
     "dqmc_timing_get": (C.c_int, [_H, _dp, _i64p]),
     "dqmc_mfma_f64_peak": (C.c_int, [C.c_int32, C.c_int32, _dp]),

@@ -8,9 +8,8 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/prof_r04
 rm -rf $OUT; mkdir -p $OUT/summary
 COMMIT=$(cat $R/profiles/r04_commit.txt 2>/dev/null || echo unknown)
+HASH=$(python3 -c "import ctypes; L = ctypes.CDLL('$R/montecarlo.jl_amd/libdqmc_hip.so'); L.dqmc_build_source_hash.restype = ctypes.c_char_p; print(L.dqmc_build_source_hash().decode())" 2>/dev/null || echo unknown)
 cd /tmp && export TMPDIR=/tmp
-echo "[profile_r04] $(date +%T) next: python3 $R/bench.py > $OUT/summary/r04_bench.json 2> $OUT/be"
-python3 $R/bench.py > $OUT/summary/r04_bench.json 2> $OUT/bench.err || echo "bench failed"
 echo "[profile_r04] $(date +%T) next: rocprofv3 --kernel-trace --stats --output-format csv -d $OUT"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/summary/r04_bench_under_rocprof.json 2> $OUT/trace.err || echo "trace run failed"
 for C in FETCH_SIZE WRITE_SIZE; do
@@ -26,7 +25,11 @@ rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 S
 echo "[profile_r04] $(date +%T) next: rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_"
 rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES -d $OUT/pmc_sq3 -- python3 $R/tools/pmc_gemm.py > /dev/null 2> $OUT/pmc_sq3.err || echo "pmc sq3 failed"
 cd $R
-python3 tools/pmc_parse.py $OUT "$COMMIT" $OUT/summary/r04_pmc_summary.json $OUT/summary/r04_pmc_gemm.json 2> $OUT/parse.err
+python3 tools/pmc_parse.py $OUT "$COMMIT" $OUT/summary/r04_pmc_summary.json $OUT/summary/r04_pmc_gemm.json "$HASH" 2> $OUT/parse.err
+# the bench line last: it reads the PMC summary just written (profiles/ on the box is this run's scratch copy)
+cp $OUT/summary/r04_pmc_summary.json $OUT/summary/r04_pmc_gemm.json $R/profiles/
+echo "[profile_r04] $(date +%T) next: python3 $R/bench.py > $OUT/summary/r04_bench.json"
+python3 $R/bench.py > $OUT/summary/r04_bench.json 2> $OUT/bench.err || echo "bench failed"
 ST=$(find $OUT/trace -name "*kernel_stats.csv" | head -1)
-if [ -n "$ST" ]; then (echo "# rocprofv3 --kernel-trace --stats of: bench.py --steps 5 --warmup 1 --no-cpu-baseline; library built from commit $COMMIT"; cat $ST) > $OUT/summary/r04_kernel_stats.csv; fi
+if [ -n "$ST" ]; then (echo "# rocprofv3 --kernel-trace --stats of: bench.py --steps 5 --warmup 1 --no-cpu-baseline; library built from commit $COMMIT, kernel source hash $HASH"; cat $ST) > $OUT/summary/r04_kernel_stats.csv; fi
 ls $OUT/summary
