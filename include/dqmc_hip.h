@@ -289,9 +289,10 @@ int dqmc_calculate_greens(int32_t device_id, int32_t n, int32_t batch, const dou
 int dqmc_set_checkerboard(dqmc_handle *h, int32_t kmax, int32_t n_mats, const double *vals, const int32_t *cols,
                           const double *mu, const double *mu_inv, const int32_t *seqs, const int32_t *lens);
 
-/* The cooperative QR (8 workgroups per matrix, bounded hand-off spins) leaves its input intact; if a launch times
- * out (CUs held by another stream for longer than the spins allow), the guarded single-workgroup kernel launched
- * behind it redoes the factorisation, so results stay valid.  This counter reports how often that happened. */
+/* The cooperative QR with the reference's pivot rule (n < 256, or 33..64 units at n = 256; 8 workgroups per matrix, bounded
+ * hand-off spins) leaves its input intact; if a launch times out (CUs held by another stream for longer than the spins allow),
+ * the guarded single-workgroup kernel launched behind it redoes the factorisation, so results stay valid.  This counter reports
+ * how often that happened.  (The one-launch UDT has no second path: its time-outs fail the call, see dqmc_device_errors.) */
 int dqmc_qr_fallbacks(dqmc_handle *h, int64_t *count);
 /* which call sites of udt_AVX_pivot! (UDT.jl:192-306) this handle serves with the one-launch pre-pivoted factorisation:
  * bit 0 add_slice_sequence_left/right (stack.jl:272-311) and other callers, bit 1 / bit 2 the two factorisations of
