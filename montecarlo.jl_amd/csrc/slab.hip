@@ -63,8 +63,8 @@ __global__ __launch_bounds__(256) void slab_chain_kernel(SlabArgs a)
     const int unit = (seq >> 3) * 8 + xcd, slab = seq & 7;
     if (unit >= a.n_units) return;
     SLAB_STAMP(0);
-    // (nb is 1 or 2 - BlockDiagonal has two blocks, blockdiagonal.jl:13-36: no integer division in the cold prologue, whose
-    // instructions cost an instruction-cache miss per 64 bytes)
+    // (nb is 1 or 2 - BlockDiagonal has two blocks, blockdiagonal.jl:13-36: a shift instead of the ~25 instructions of an
+    // integer division in front of the first requests)
     const int wk = a.nb == 2 ? unit >> 1 : unit, blk = a.nb == 2 ? unit & 1 : 0;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, ci = lane & 15;
     double *buf0 = slab_lds, *buf1 = slab_lds + SL_W * SL_LD;
