@@ -95,6 +95,25 @@ def test_cfg2_sweeps(gpu, O):
     mc.close()
 
 
+@pytest.mark.parametrize("kind,safe_mult", [("attractive", 1), ("attractive", 2), ("attractive", 5), ("repulsive", 5)])
+def test_n256_short_slice_chains(gpu, O, kind, safe_mult):
+    """n = 256 with safe_mult below 10 (beta = 1: M = 10): the slab kernel runs chains of 1, 2 and 5 products (its request
+    stream runs on into the next step's operand and wraps at the last step) and, for the repulsive model, two blocks per walker;
+    a full sweep of updates, update by update, against the oracle"""
+    mc, refs = make_pair(gpu, O, 16, kind, 1.0, n_walkers=2, safe_mult=safe_mult)
+    mc.prepare()
+    for o in refs:
+        o.prepare()
+    compare(mc, refs)
+    for u in range(2 * mc.p.slices + 1):
+        mc.update()
+        for o in refs:
+            o.update()
+        assert (mc.current_slice, mc.direction) == (refs[0].current_slice, refs[0].direction)
+        compare(mc, refs)
+    mc.close()
+
+
 def test_cfg3_one_sweep(gpu, O):
     """BASELINE config 3 shape: attractive 16x16, beta=8 (n=256, M=80), 2 walkers, 1 sweep"""
     mc, refs = make_pair(gpu, O, 16, "attractive", 8.0, n_walkers=2)
