@@ -29,6 +29,22 @@ def test_header_symbols_exported(mc_amd):
     assert sorted(_lib.SIGNATURES) == names, "ctypes binding and header disagree"
 
 
+def test_library_is_built_from_the_sources_in_the_tree(mc_amd):
+    """dqmc_build_source_hash() (csrc/Makefile: SOURCE_HASH) restated: sha256 over the sorted csrc/*.hip, *.h, *.inl, engine.cpp,
+    then the Makefile and the assembly patcher.  A library left over from other sources (the .so is not in git: it travels to
+    the GPU box as built) fails here instead of being measured; the same hash decides whether bench.py calls a committed
+    profile stale"""
+    import glob, hashlib
+    from montecarlo_jl_amd import _lib
+    csrc = os.path.join(ROOT, "montecarlo.jl_amd", "csrc")
+    files = sorted(set(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")) +
+                       glob.glob(os.path.join(csrc, "*.inl")) + [os.path.join(csrc, "engine.cpp")]), key=os.path.basename)
+    h = hashlib.sha256()
+    for f in files + [os.path.join(csrc, "Makefile"), os.path.join(ROOT, "tools", "scan_mfma_war.py")]:
+        h.update(open(f, "rb").read())
+    assert _lib.lib().dqmc_build_source_hash().decode() == h.hexdigest()[:12]
+
+
 def test_no_device_and_argument_errors(mc_amd):
     from montecarlo_jl_amd import _lib
     lib = _lib.lib()
