@@ -634,6 +634,7 @@ __device__ __forceinline__ void qrb_own(d4 (&c)[8], d4 (&z)[8], const QbLds &L, 
 #endif
     QB_BARRIER();
     QRB_STAMP(53);
+    if (wv == 0) qrb_tcolumn<W>(L, mb, tag, local, lane, 31);  // (first: the next owner is waiting for this column of T)
     {
         const double *zs = L.Vs + tid;
 #pragma unroll
@@ -641,7 +642,6 @@ __device__ __forceinline__ void qrb_own(d4 (&c)[8], d4 (&z)[8], const QbLds &L, 
 #pragma unroll
             for (int q = 0; q < 4; ++q) z[u][q] = zs[(4 * u + q) * 256];
     }
-    if (wv == 0) qrb_tcolumn<W>(L, mb, tag, local, lane, 31);
     // T = D^-1 R of my column: rows <= its position (UDT.jl:283-306), zeros below.  Rows above the panel are in x, the rows of
     // the diagonal block above the diagonal in r, the diagonal entry is -nu
     {
