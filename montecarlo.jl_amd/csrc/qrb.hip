@@ -203,7 +203,11 @@ struct QbLds {
 // HALF = 0 / 1: only reflectors 16 HALF .. 16 HALF + 15 with the diagonal block of T that belongs to them (the panel's block
 // reflector is the product of its two halves' block reflectors: the next owner applies the first half while the second is
 // still being factored)
-template <int P, int HALF = -1>
+// POLL = false: no separate poll - the batch itself is repeated until every tag is current.  For the hand-off the next owner
+// waits for (one trip to the L2 less between the owner's last store and the first MFMA: 1.4 us per hand-off) and for panels that
+// were published long ago; the other waits keep the light poll on one granule (a waiting workgroup that repeated the whole
+// batch would put 64-128 KB per pass on the L2 the owners publish through)
+template <int P, int HALF = -1, bool POLL = true>
 __device__ __forceinline__ void qrb_fetch(const qword *mb, unsigned tag, const QbLds &L, int tid)
 {
     constexpr int C0 = HALF < 0 ? 0 : 16 * HALF, NC = HALF < 0 ? 32 : 16;  // reflectors C0 .. C0 + NC - 1
@@ -219,7 +223,7 @@ __device__ __forceinline__ void qrb_fetch(const qword *mb, unsigned tag, const Q
     const qword *tmine = tb + 2L * (tcol * 32 + trow);
     const qword *dmine = mb + 2 * (MB_D + 32 * P + C0 + (tid & (NC - 1)));
     QRB_STAMP(8 + 4 * P + 0);
-    (void)g_wait(tb + 2L * ((C0 + NC - 1) * 32 + C0 + NC - 1), tag, L.s_abort);
+    if (POLL) (void)g_wait(tb + 2L * ((C0 + NC - 1) * 32 + C0 + NC - 1), tag, L.s_abort);
     QRB_STAMP(8 + 4 * P + 1);
     for (unsigned s = 0; s < QB_SPIN; ++s) {
         bool ok = true;
@@ -680,12 +684,12 @@ __device__ __forceinline__ void qrb_panel(d4 (&c)[8], d4 (&z)[8], const QbLds &L
         qrb_own<P>(c, z, L, mb, tag, local, tid, Tout, apply_pivot, force_timeout, W);
         QB_BARRIER();
         if (P > 0) {  // the update of Z that made way for my panel: its second half (the first went in while I waited, below)
-            qrb_fetch<(P > 0 ? P - 1 : 0), 1>(mb, tag, L, tid);
+            qrb_fetch<(P > 0 ? P - 1 : 0), 1, false>(mb, tag, L, tid);  // (published long ago: nothing to poll for)
             qrb_apply<(P > 0 ? P - 1 : 0), false, true, 1>(c, z, L, wv, lane);
         }
     }
     if (P >= W) {
-        qrb_fetch<P>(mb, tag, L, tid);
+        qrb_fetch<P, -1, (P != W)>(mb, tag, L, tid);  // (my own panel is there already)
         qrb_apply<P, false, true>(c, z, L, wv, lane);
     } else if (P == W - 1) {
         // I am the next owner: the first 16 reflectors are applied while the second 16 are still being factored
@@ -694,7 +698,7 @@ __device__ __forceinline__ void qrb_panel(d4 (&c)[8], d4 (&z)[8], const QbLds &L
         // Z takes the same 16 reflectors now, in the time I would spend waiting for the other 16 (≈10 us of the owner's steps
         // against ≈5 us for both applications): half of the deferred update leaves the tail behind my own panel
         qrb_apply<P, false, true, 0>(c, z, L, wv, lane);
-        qrb_fetch<P, 1>(mb, tag, L, tid);
+        qrb_fetch<P, 1, false>(mb, tag, L, tid);
         qrb_apply<P, true, false, 1>(c, z, L, wv, lane);
 #ifdef QRB_X_DUMP
         if (W == 1) {
