@@ -1,5 +1,5 @@
-"""In-kernel timeline of qrb_udt_kernel (the eight parts of unit 0): build with `make -C montecarlo.jl_amd/csrc stamps`, run with
-DQMC_HIP_LIB=montecarlo.jl_amd/libdqmc_hip_stamps.so python tools/qrb_stamps.py"""
+"""In-kernel timeline of qrb_udt_kernel (the eight parts of unit 0): build with `make -C montecarlo.jl_amd/csrc -f diag.mk qrb_stamps`, run with
+DQMC_HIP_LIB=montecarlo.jl_amd/libdqmc_hip_qrbstamps.so python tools/qrb_stamps.py"""
 import ctypes as C, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
